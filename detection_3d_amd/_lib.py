@@ -1,0 +1,126 @@
+"""ctypes binding of libd3d_hip.so (include/d3d_hip.h).  There is NO CPU fallback: if the HIP
+library is missing or fails to load, importing an op raises."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libd3d_hip.so")
+
+_lib = None
+
+c_int_p = ctypes.POINTER(ctypes.c_int)
+vp = ctypes.c_void_p
+
+_SIGS = {
+    "d3d_last_error": (ctypes.c_char_p, []),
+    "d3d_abi_version": (ctypes.c_int, []),
+    "d3d_meta_create": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.c_size_t]),
+    "d3d_meta_destroy": (ctypes.c_int, [vp]),
+    "d3d_meta_clear": (ctypes.c_int, [vp]),
+    "d3d_meta_arena_used": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_size_t)]),
+    "d3d_voxelize": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_int_p, vp, vp,
+                                    c_int_p, vp, ctypes.c_size_t, vp]),
+    "d3d_voxelize_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "d3d_input_layer_build": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, c_int_p, ctypes.c_int,
+                                             ctypes.c_int, vp, c_int_p]),
+    "d3d_input_layer_forward": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, vp]),
+    "d3d_input_layer_export": (ctypes.c_int, [vp, vp, vp, vp]),
+    "d3d_get_n_active": (ctypes.c_int, [vp, c_int_p, c_int_p]),
+    "d3d_get_spatial_locations": (ctypes.c_int, [vp, c_int_p, vp, vp]),
+    "d3d_subm_prepare": (ctypes.c_int, [vp, c_int_p, c_int_p, vp, ctypes.POINTER(ctypes.c_long)]),
+    "d3d_conv_prepare": (ctypes.c_int, [vp, c_int_p, c_int_p, c_int_p, c_int_p, vp, c_int_p,
+                                        ctypes.POINTER(ctypes.c_long)]),
+    "d3d_export_rules": (ctypes.c_int, [vp, ctypes.c_int, c_int_p, c_int_p, c_int_p, vp, ctypes.c_long,
+                                        ctypes.POINTER(ctypes.c_long), vp]),
+    "d3d_packed_weight_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "d3d_pack_conv_weight": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "d3d_subm_conv_forward": (ctypes.c_int, [vp, c_int_p, c_int_p, vp, ctypes.c_int, vp, ctypes.c_int, vp,
+                                             vp, vp, ctypes.POINTER(ctypes.c_double)]),
+    "d3d_conv_forward": (ctypes.c_int, [vp, c_int_p, c_int_p, c_int_p, c_int_p, vp, ctypes.c_int, vp,
+                                        ctypes.c_int, vp, vp, ctypes.POINTER(ctypes.c_double)]),
+    "d3d_deconv_forward": (ctypes.c_int, [vp, c_int_p, c_int_p, c_int_p, c_int_p, vp, ctypes.c_int, vp,
+                                          ctypes.c_int, vp, vp, vp, ctypes.POINTER(ctypes.c_double)]),
+    "d3d_bn_forward": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp,
+                                      ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_float, vp,
+                                      ctypes.c_size_t, vp]),
+    "d3d_bn_batch_stats": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_size_t, vp]),
+    "d3d_bn_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "d3d_add": (ctypes.c_int, [vp, vp, vp, ctypes.c_size_t, vp]),
+    "d3d_sparse_to_dense_forward": (ctypes.c_int, [vp, c_int_p, vp, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "d3d_roi_align_rotated_3d_forward": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                        ctypes.c_int, ctypes.c_int, vp, ctypes.c_int,
+                                                        ctypes.c_float, ctypes.c_int, ctypes.c_int,
+                                                        ctypes.c_int, ctypes.c_int, vp, vp]),
+    "d3d_roi_align_rotated_3d_sparse_forward": (ctypes.c_int, [vp, c_int_p, vp, ctypes.c_int, c_int_p, vp,
+                                                               ctypes.c_int, ctypes.c_float, ctypes.c_int,
+                                                               ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                               vp, vp]),
+    "d3d_rotate_iou_eval": (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "d3d_boxes_iou_3d": (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
+                                        ctypes.c_int, ctypes.c_int, vp, vp]),
+    "d3d_rotate_nms_3d_sorted": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_float, vp, vp, vp,
+                                                ctypes.c_size_t, vp]),
+    "d3d_nms_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "d3d_box_decode": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.c_float,
+                                      vp, vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS.keys())
+
+
+class D3DError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads the HIP library; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise D3DError(
+                f"{LIB_PATH} not found: build it with `python -m detection_3d_amd.build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().d3d_last_error()
+        raise D3DError(f"libd3d_hip error {rc}: {msg.decode() if msg else ''}")
+
+
+def ints(values):
+    values = [int(v) for v in values]
+    return (ctypes.c_int * len(values))(*values)
+
+
+def floats(values):
+    values = [float(v) for v in values]
+    return (ctypes.c_float * len(values))(*values)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_of(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise D3DError("this op runs on the MI355X only: tensor is on %s (no CPU fallback)" % t.device)
+        if t is not None and not t.is_contiguous():
+            raise D3DError("tensor must be contiguous")

@@ -1,0 +1,467 @@
+// a14-a18. Rotated BEV IoU x z-interval IoU, greedy rotated NMS, box decode -- all on device.
+// The reference bounces GPU -> numpy -> numba-CUDA -> numpy -> spconv C++ -> GPU
+// (utils3d/rotate_nms_3d_torch.py:64-83, second/core/non_max_suppression/nms_cpu.py:35-43).
+//
+// Arithmetic contract (shared with the oracle, compiled with -ffp-contract=off): fp32 for the
+// geometry of second/core/non_max_suppression/nms_gpu.py, fp64 for the triangle-fan sum and the
+// final ratio (numba promotes `x / 2.0`), cos/sin evaluated in fp64 and rounded to fp32.
+#include "d3d_internal.h"
+
+namespace d3d {
+
+struct Quad {
+  float p[8];  // 4 corners (x,y), order of rbbox_to_corners (nms_gpu.py:355-378)
+};
+
+__device__ __forceinline__ Quad make_quad(float xc, float yc, float xd, float yd, float angle) {
+  const float a_cos = (float)cos((double)angle);
+  const float a_sin = (float)sin((double)angle);
+  const float cx[4] = {-xd / 2, -xd / 2, xd / 2, xd / 2};
+  const float cy[4] = {-yd / 2, yd / 2, yd / 2, -yd / 2};
+  Quad q;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    q.p[2 * i] = a_cos * cx[i] + a_sin * cy[i] + xc;
+    q.p[2 * i + 1] = -a_sin * cx[i] + a_cos * cy[i] + yc;
+  }
+  return q;
+}
+
+// nms_gpu.py:310-328
+__device__ __forceinline__ bool point_in_quad(float px, float py, const float *c) {
+  const float ab0 = c[2] - c[0], ab1 = c[3] - c[1];
+  const float ad0 = c[6] - c[0], ad1 = c[7] - c[1];
+  const float ap0 = px - c[0], ap1 = py - c[1];
+  const float abab = ab0 * ab0 + ab1 * ab1;
+  const float abap = ab0 * ap0 + ab1 * ap1;
+  const float adad = ad0 * ad0 + ad1 * ad1;
+  const float adap = ad0 * ap0 + ad1 * ap1;
+  return abab >= abap && abap >= 0 && adad >= adap && adap >= 0;
+}
+
+// nms_gpu.py:222-265
+__device__ __forceinline__ bool seg_intersect(const float *p1, const float *p2, int i, int j,
+                                              float *out) {
+  const float A0 = p1[2 * i], A1 = p1[2 * i + 1];
+  const float B0 = p1[2 * ((i + 1) & 3)], B1 = p1[2 * ((i + 1) & 3) + 1];
+  const float C0 = p2[2 * j], C1 = p2[2 * j + 1];
+  const float D0 = p2[2 * ((j + 1) & 3)], D1 = p2[2 * ((j + 1) & 3) + 1];
+  const float BA0 = B0 - A0, BA1 = B1 - A1;
+  const float DA0 = D0 - A0, CA0 = C0 - A0;
+  const float DA1 = D1 - A1, CA1 = C1 - A1;
+  const bool acd = DA1 * CA0 > CA1 * DA0;
+  const bool bcd = (D1 - B1) * (C0 - B0) > (C1 - B1) * (D0 - B0);
+  if (acd == bcd) return false;
+  const bool abc = CA1 * BA0 > BA1 * CA0;
+  const bool abd = DA1 * BA0 > BA1 * DA0;
+  if (abc == abd) return false;
+  const float DC0 = D0 - C0, DC1 = D1 - C1;
+  const float ABBA = A0 * B1 - B0 * A1;
+  const float CDDC = C0 * D1 - D0 * C1;
+  const float DH = BA1 * DC0 - BA0 * DC1;
+  const float Dx = ABBA * DC0 - BA0 * CDDC;
+  const float Dy = ABBA * DC1 - BA1 * CDDC;
+  out[0] = Dx / DH;
+  out[1] = Dy / DH;
+  return true;
+}
+
+// inter() of nms_gpu.py:381-395 on precomputed corners: q1 = rbbox1, q2 = rbbox2.
+__device__ double quad_inter_f32(const Quad &q1, const Quad &q2) {
+  float pts[48];
+  int num = 0;
+  // nms_gpu.py:331-352
+  for (int i = 0; i < 4; i++) {
+    if (point_in_quad(q1.p[2 * i], q1.p[2 * i + 1], q2.p)) {
+      pts[num * 2] = q1.p[2 * i];
+      pts[num * 2 + 1] = q1.p[2 * i + 1];
+      num++;
+    }
+    if (point_in_quad(q2.p[2 * i], q2.p[2 * i + 1], q1.p)) {
+      pts[num * 2] = q2.p[2 * i];
+      pts[num * 2 + 1] = q2.p[2 * i + 1];
+      num++;
+    }
+  }
+  float tmp[2];
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++)
+      if (seg_intersect(q1.p, q2.p, i, j, tmp)) {
+        pts[num * 2] = tmp[0];
+        pts[num * 2 + 1] = tmp[1];
+        num++;
+      }
+  if (num < 3) return 0.0;
+  // nms_gpu.py:182-219
+  float cx = 0.f, cy = 0.f;
+  for (int i = 0; i < num; i++) {
+    cx += pts[2 * i];
+    cy += pts[2 * i + 1];
+  }
+  cx = (float)((double)cx / num);
+  cy = (float)((double)cy / num);
+  float vs[24];
+  for (int i = 0; i < num; i++) {
+    float v0 = pts[2 * i] - cx, v1 = pts[2 * i + 1] - cy;
+    const float d = sqrtf(v0 * v0 + v1 * v1);
+    v0 = v0 / d;
+    v1 = v1 / d;
+    if (v1 < 0) v0 = -2 - v0;
+    vs[i] = v0;
+  }
+  for (int i = 1; i < num; i++) {
+    if (vs[i - 1] > vs[i]) {
+      const float temp = vs[i], tx = pts[2 * i], ty = pts[2 * i + 1];
+      int j = i;
+      while (j > 0 && vs[j - 1] > temp) {
+        vs[j] = vs[j - 1];
+        pts[j * 2] = pts[j * 2 - 2];
+        pts[j * 2 + 1] = pts[j * 2 - 1];
+        j--;
+      }
+      vs[j] = temp;
+      pts[j * 2] = tx;
+      pts[j * 2 + 1] = ty;
+    }
+  }
+  // nms_gpu.py:166-179
+  double area = 0.0;
+  for (int i = 0; i < num - 2; i++) {
+    const float *a = pts, *b = pts + 2 * i + 2, *c = pts + 2 * i + 4;
+    const float v = (a[0] - c[0]) * (b[1] - c[1]) - (a[1] - c[1]) * (b[0] - c[0]);
+    area += fabs((double)v / 2.0);
+  }
+  return area;
+}
+
+// devRotateIoUEval (nms_gpu.py:552-570): rbox1 = (q1, dims d1a x d1b), rbox2 likewise.
+__device__ __forceinline__ float iou_eval(const Quad &q1, float d1a, float d1b, const Quad &q2,
+                                          float d2a, float d2b, int criterion) {
+  const float area1 = d1a * d1b, area2 = d2a * d2b;
+  const double ai = quad_inter_f32(q1, q2);
+  if (criterion == -1) return (float)(ai / ((double)(area1 + area2) - ai));
+  if (criterion == 0) return (float)(ai / area1);
+  if (criterion == 1) return (float)(ai / area2);
+  if (criterion == 2) {
+    const bool small = fminf(d2a, d2b) / fmaxf(d2a, d2b) < 0.25;
+    if (small) return (float)(ai / ((double)area2 + fmax(0.0, (double)area1 * 0.5 - ai)));
+    return (float)(ai / ((double)(area1 + area2) - ai));
+  }
+  return (float)ai;
+}
+
+// fp64 Sutherland-Hodgman clip of quad P by quad Q (both fp32 corners); returns the area.
+__device__ double quad_inter_f64(const float *P, const float *Q) {
+  double a[32], b[32];
+  int na = 4;
+  for (int i = 0; i < 8; i++) a[i] = P[i];
+  double sq = 0;
+  for (int i = 0; i < 4; i++) {
+    const int j = (i + 1) & 3;
+    sq += (double)Q[2 * i] * Q[2 * j + 1] - (double)Q[2 * j] * Q[2 * i + 1];
+  }
+  const double sgn = sq >= 0 ? 1.0 : -1.0;
+  for (int e = 0; e < 4 && na > 0; e++) {
+    const double x1 = Q[2 * e], y1 = Q[2 * e + 1];
+    const double x2 = Q[2 * ((e + 1) & 3)], y2 = Q[2 * ((e + 1) & 3) + 1];
+    int nb = 0;
+    for (int i = 0; i < na; i++) {
+      const int j = (i + 1) % na;
+      const double cx = a[2 * i], cy = a[2 * i + 1], nx = a[2 * j], ny = a[2 * j + 1];
+      const double dc = sgn * ((x2 - x1) * (cy - y1) - (y2 - y1) * (cx - x1));
+      const double dn = sgn * ((x2 - x1) * (ny - y1) - (y2 - y1) * (nx - x1));
+      if (dc >= 0) {
+        b[2 * nb] = cx;
+        b[2 * nb + 1] = cy;
+        nb++;
+      }
+      if ((dc >= 0) != (dn >= 0)) {
+        const double t = dc / (dc - dn);
+        b[2 * nb] = cx + t * (nx - cx);
+        b[2 * nb + 1] = cy + t * (ny - cy);
+        nb++;
+      }
+    }
+    na = nb;
+    for (int i = 0; i < 2 * nb; i++) a[i] = b[i];
+  }
+  if (na < 3) return 0.0;
+  double s = 0;
+  for (int i = 0; i < na; i++) {
+    const int j = (i + 1) % na;
+    s += a[2 * i] * a[2 * j + 1] - a[2 * j] * a[2 * i + 1];
+  }
+  return fabs(s) * 0.5;
+}
+__device__ __forceinline__ double quad_area_f64(const float *P) {
+  double s = 0;
+  for (int i = 0; i < 4; i++) {
+    const int j = (i + 1) & 3;
+    s += (double)P[2 * i] * P[2 * j + 1] - (double)P[2 * j] * P[2 * i + 1];
+  }
+  return fabs(s) * 0.5;
+}
+
+// ------------------------------------------------------------------------------------------
+// IoU matrix: 64 x 64 tile per 256-thread block; lane = column (coalesced stores).
+// mode 0: rotate_iou_gpu_eval on [*,5] boxes.  mode 1: boxes_iou_3d on [*,7] yx_zb boxes.
+struct IouArgs {
+  const float *rows;  // "boxes"/"targets"  [N, stride]
+  const float *cols;  // "query"/"anchors"  [K, stride]
+  int N, K, mode, criterion, only_xy;
+  float aug[4];
+  float *out;
+};
+struct BoxRec {
+  Quad q;
+  float d0, d1, z0, z1;
+  float raw[5];
+};
+__device__ __forceinline__ void load_box(const IouArgs &a, const float *base, int idx, bool is_row,
+                                         BoxRec &r) {
+  float xc, yc, d0, d1, ang;
+  if (a.mode == 0) {
+    const float *b = base + (size_t)idx * 5;
+    xc = b[0]; yc = b[1]; d0 = b[2]; d1 = b[3]; ang = b[4];
+    r.z0 = 0.f; r.z1 = 1.f;
+  } else {
+    const float *b = base + (size_t)idx * 7;
+    const float cy = is_row ? a.aug[0] : a.aug[2], cz = is_row ? a.aug[1] : a.aug[3];
+    xc = b[0]; yc = b[1]; d0 = fmaxf(b[3], cy); d1 = b[4]; ang = b[6];
+    const float dz = fmaxf(b[5], cz);
+    r.z0 = b[2];
+    r.z1 = b[2] + dz;  // rotate_nms_3d_torch.py:15-16
+  }
+  r.d0 = d0; r.d1 = d1;
+  r.raw[0] = xc; r.raw[1] = yc; r.raw[2] = d0; r.raw[3] = d1; r.raw[4] = ang;
+  r.q = make_quad(xc, yc, d0, d1, ang);
+}
+
+__global__ __launch_bounds__(256) void k_iou_matrix(IouArgs a) {
+  __shared__ BoxRec srow[64], scol[64];
+  const int tid = threadIdx.x;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  if (tid < 64) {
+    if (r0 + tid < a.N) load_box(a, a.rows, r0 + tid, true, srow[tid]);
+  } else if (tid < 128) {
+    const int t = tid - 64;
+    if (c0 + t < a.K) load_box(a, a.cols, c0 + t, false, scol[t]);
+  }
+  __syncthreads();
+  const int c = tid & 63, rg = tid >> 6;
+  if (c0 + c >= a.K) return;
+  const BoxRec &cb = scol[c];
+  for (int i = 0; i < 16; i++) {
+    const int rr = rg * 16 + i;
+    if (r0 + rr >= a.N) break;
+    const BoxRec &rb = srow[rr];
+    // kernel order (nms_gpu.py:605-611): rbox1 = query (col), rbox2 = box (row)
+    float v = iou_eval(cb.q, cb.d0, cb.d1, rb.q, rb.d0, rb.d1, a.criterion);
+    bool same = true;  // check_same_boxes, nms_gpu.py:653-664
+#pragma unroll
+    for (int d = 0; d < 5; d++) same = same && (fabsf(rb.raw[d] - cb.raw[d]) < (float)1e-6);
+    if (same) v = 1.f;
+    if (a.mode == 1 && !a.only_xy) {
+      const float overlap = fminf(cb.z1, rb.z1) - fmaxf(cb.z0, rb.z0);
+      const float common = fmaxf(cb.z1, rb.z1) - fminf(cb.z0, rb.z0);
+      v = v * (overlap / common);
+    }
+    a.out[(size_t)(r0 + rr) * a.K + c0 + c] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// NMS suppression masks: one wave per 64 x 64 tile; lanes = candidate boxes j; __ballot packs the
+// 64 decisions "i suppresses j" of row i into one 64-bit word (wave64).
+struct NmsBox {
+  Quad q;
+  float d0, d1, z0, z1, raw[5];
+  double area;
+};
+__global__ void k_nms_prep(const float *__restrict__ boxes, int n, NmsBox *__restrict__ rec) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float *b = boxes + (size_t)i * 7;
+  NmsBox r;
+  r.d0 = b[3]; r.d1 = b[4];
+  r.z0 = b[2]; r.z1 = b[2] + b[5];
+  r.raw[0] = b[0]; r.raw[1] = b[1]; r.raw[2] = b[3]; r.raw[3] = b[4]; r.raw[4] = b[6];
+  r.q = make_quad(b[0], b[1], b[3], b[4], b[6]);
+  r.area = quad_area_f64(r.q.p);
+  rec[i] = r;
+}
+__global__ __launch_bounds__(64) void k_nms_mask(const NmsBox *__restrict__ rec, int n, int ncb,
+                                                 float thresh,
+                                                 unsigned long long *__restrict__ mask) {
+  const int rt = blockIdx.y, ct = blockIdx.x;
+  if (ct < rt) return;
+  __shared__ NmsBox srow[64];
+  const int lane = threadIdx.x;
+  if (rt * 64 + lane < n) srow[lane] = rec[rt * 64 + lane];
+  const int j = ct * 64 + lane;
+  NmsBox cb;
+  if (j < n) cb = rec[j];
+  __syncthreads();
+  const int nrow = min(64, n - rt * 64);
+  for (int ii = 0; ii < nrow; ii++) {
+    const int i = rt * 64 + ii;
+    bool sup = false;
+    if (j < n && j > i) {
+      const NmsBox &rb = srow[ii];
+      // gate = boxes_iou_3d(dets, dets)[i, j] > 0 (nms_cpu.py:35, spconv nms.h)
+      float v = iou_eval(cb.q, cb.d0, cb.d1, rb.q, rb.d0, rb.d1, -1);
+      bool same = true;
+#pragma unroll
+      for (int d = 0; d < 5; d++) same = same && (fabsf(rb.raw[d] - cb.raw[d]) < (float)1e-6);
+      if (same) v = 1.f;
+      const float overlap = fminf(cb.z1, rb.z1) - fmaxf(cb.z0, rb.z0);
+      const float common = fmaxf(cb.z1, rb.z1) - fminf(cb.z0, rb.z0);
+      v = v * (overlap / common);
+      if (v > 0.0f) {
+        const double ia = quad_inter_f64(rb.q.p, cb.q.p);
+        if (ia > 0) {
+          const double ua = rb.area + cb.area - ia;
+          sup = ua > 0 && ia / ua >= (double)thresh;
+        }
+      }
+    }
+    const unsigned long long w = __ballot(sup);
+    if (lane == 0) mask[(size_t)i * ncb + ct] = w;
+  }
+}
+// Greedy sweep by ONE wave: lane w owns word w of the "removed" bit vector.  Per 64-box chunk the
+// intra-chunk chain is resolved on the diagonal words with readlane, then the kept rows' words
+// are OR-ed in with independent loads.
+__global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long *__restrict__ mask, int n,
+                                                  int ncb, int32_t *__restrict__ keep,
+                                                  int32_t *__restrict__ n_keep) {
+  const int lane = threadIdx.x;
+  unsigned long long removed = 0;  // word `lane`
+  int cnt = 0;
+  for (int c = 0; c < ncb; c++) {
+    const int base = c * 64;
+    const int nrow = min(64, n - base);
+    unsigned long long diag = 0;
+    if (lane < nrow) diag = mask[(size_t)(base + lane) * ncb + c];
+    unsigned long long alive = ~__shfl(removed, c, 64);
+    if (nrow < 64) alive &= (1ull << nrow) - 1ull;
+    unsigned long long kept = 0;
+    for (int b = 0; b < nrow; b++) {
+      const unsigned long long d = __shfl(diag, b, 64);
+      if ((alive >> b) & 1ull) {
+        kept |= 1ull << b;
+        alive &= ~d;
+      }
+    }
+    unsigned long long k = kept;
+    while (k) {
+      const int b = __builtin_ctzll(k);
+      k &= k - 1;
+      if (lane == 0) keep[cnt] = base + b;
+      cnt++;
+      if (lane >= c && lane < ncb) removed |= mask[(size_t)(base + b) * ncb + lane];
+    }
+  }
+  if (lane == 0) *n_keep = cnt;
+}
+
+// a14. BoxCoder3D.decode
+__global__ void k_box_decode(const float *__restrict__ enc, const float *__restrict__ anchors, int n,
+                             float w0, float w1, float w2, float w3, float w4, float w5, float w6,
+                             float clip, float *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float *e = enc + (size_t)i * 7, *a = anchors + (size_t)i * 7;
+  const float w[7] = {w0, w1, w2, w3, w4, w5, w6};
+  float t[7];
+#pragma unroll
+  for (int k = 0; k < 7; k++) t[k] = e[k] / w[k];
+#pragma unroll
+  for (int k = 3; k < 6; k++) t[k] = fminf(t[k], clip);
+  const float xa = a[0], ya = a[1], za = a[2], wa = a[3], la = a[4], ha = a[5], ra = a[6];
+  const float diagonal = sqrtf(la * la + wa * wa);
+  float *o = out + (size_t)i * 7;
+  o[0] = t[0] * diagonal + xa;
+  o[1] = t[1] * diagonal + ya;
+  o[2] = t[2] * ha + za;
+  o[3] = (t[3] + 1) * wa;
+  o[4] = (t[4] + 1) * la;
+  o[5] = (t[5] + 1) * ha;
+  const float pi = 3.14159265358979323846f;
+  const float rg = t[6] + ra;
+  o[6] = rg - floorf(rg / pi + 0.5f) * pi;
+}
+
+}  // namespace d3d
+
+using namespace d3d;
+
+extern "C" {
+
+int d3d_rotate_iou_eval(const float *boxes, int N, const float *query, int K, int criterion,
+                        float *out, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(N >= 0 && K >= 0, "rotate_iou_eval: negative size");
+  if (N == 0 || K == 0) return D3D_OK;
+  D3D_REQUIRE(boxes && query && out, "rotate_iou_eval: null pointer");
+  IouArgs a;
+  a.rows = boxes; a.cols = query; a.N = N; a.K = K; a.mode = 0; a.criterion = criterion; a.only_xy = 1;
+  a.aug[0] = a.aug[1] = a.aug[2] = a.aug[3] = 0.f;
+  a.out = out;
+  hipLaunchKernelGGL(k_iou_matrix, dim3((K + 63) / 64, (N + 63) / 64), dim3(256), 0, s, a);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+int d3d_boxes_iou_3d(const float *targets, int M, const float *anchors, int N, const float *aug_host,
+                     int criterion, int only_xy, float *out, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(M >= 0 && N >= 0, "boxes_iou_3d: negative size");
+  if (M == 0 || N == 0) return D3D_OK;
+  D3D_REQUIRE(targets && anchors && out, "boxes_iou_3d: null pointer");
+  IouArgs a;
+  a.rows = targets; a.cols = anchors; a.N = M; a.K = N; a.mode = 1; a.criterion = criterion; a.only_xy = only_xy;
+  for (int i = 0; i < 4; i++) a.aug[i] = aug_host ? aug_host[i] : 0.f;
+  a.out = out;
+  hipLaunchKernelGGL(k_iou_matrix, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, s, a);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+size_t d3d_nms_scratch_bytes(int n) {
+  size_t ncb = ((size_t)n + 63) / 64;
+  return (size_t)n * ncb * 8 + (size_t)n * sizeof(NmsBox) + 1024;
+}
+
+int d3d_rotate_nms_3d_sorted(const float *boxes, int n, float thresh, int32_t *keep, int32_t *n_keep,
+                             void *scratch, size_t scratch_bytes, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(n >= 0 && n <= 4096, "rotate_nms_3d: n=%d out of range (<= 4096)", n);
+  D3D_REQUIRE(n_keep, "rotate_nms_3d: null n_keep");
+  if (n == 0) {
+    D3D_HIP_CHECK(hipMemsetAsync(n_keep, 0, sizeof(int32_t), s));
+    return D3D_OK;
+  }
+  D3D_REQUIRE(boxes && keep && scratch && scratch_bytes >= d3d_nms_scratch_bytes(n), "rotate_nms_3d: bad buffers");
+  const int ncb = (n + 63) / 64;
+  unsigned long long *mask = (unsigned long long *)scratch;
+  NmsBox *rec = (NmsBox *)((char *)scratch + (((size_t)n * ncb * 8 + 255) & ~size_t(255)));
+  hipLaunchKernelGGL(k_nms_prep, dim3((n + 127) / 128), dim3(128), 0, s, boxes, n, rec);
+  hipLaunchKernelGGL(k_nms_mask, dim3(ncb, ncb), dim3(64), 0, s, rec, n, ncb, thresh, mask);
+  hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(64), 0, s, mask, n, ncb, keep, n_keep);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+int d3d_box_decode(const float *enc, const float *anchors, int n, const float *weights_host,
+                   float clip, float *out, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) return D3D_OK;
+  D3D_REQUIRE(enc && anchors && out && weights_host && n > 0, "box_decode: bad arguments");
+  const float *w = weights_host;
+  hipLaunchKernelGGL(k_box_decode, dim3((n + 255) / 256), dim3(256), 0, s, enc, anchors, n, w[0], w[1], w[2], w[3], w[4], w[5], w[6], clip, out);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+}  // extern "C"

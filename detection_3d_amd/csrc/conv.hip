@@ -1,0 +1,251 @@
+// a6. Sparse convolution forward as ONE output-stationary launch per layer (the reference issues
+// one kernel + one blocking rule memcpy per filter offset, SCN/CUDA/RuleBookIterator.h:15-32).
+//
+// Work decomposition: a wave owns a block of 32 output rows (rows sorted by neighbour mask, see
+// grid.hip finalize_plan) and ALL Cout columns.  For every filter offset k present in the
+// block's mask it gathers the 32 input rows into its private LDS tile (full rows, 16 B per lane,
+// coalesced), then runs v_mfma_f32_32x32x2_f32 over Cin with the B operand (packed weights,
+// L2-resident) read straight from global memory.  Accumulators stay in registers across all
+// offsets; every output row is written exactly once (no atomics, deterministic).
+// Waves never synchronise with each other (no s_barrier).
+#include "d3d_internal.h"
+
+namespace d3d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // LDS operations of one wave execute in issue order; this only stops the compiler from
+  // moving LDS accesses of different lanes across the hand-off point.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+static inline int padded_cin(int cin) {
+  if (cin <= 16) return 16;
+  if (cin <= 32) return 32;
+  if (cin <= 64) return 64;
+  if (cin <= 128) return 128;
+  if (cin <= 256) return 256;
+  return -1;
+}
+
+// packed[k][g][co][j] = w[k][4g+j][co]  (zero for 4g+j >= cin)
+__global__ void k_pack_weight(const float *__restrict__ w, int fv, int cin, int cout, int cp,
+                              float *__restrict__ packed) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)fv * cp * cout;
+  if (t >= total) return;
+  int j = (int)(t & 3);
+  long u = t >> 2;
+  int co = (int)(u % cout);
+  u /= cout;
+  int g = (int)(u % (cp / 4));
+  int k = (int)(u / (cp / 4));
+  int ci = 4 * g + j;
+  packed[t] = ci < cin ? w[((size_t)k * cin + ci) * cout + co] : 0.f;
+}
+
+template <int CT, int NCT, int COUT, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_conv(
+    const float *__restrict__ in, int cin, const float *__restrict__ wp,
+    const int32_t *__restrict__ nbrT, int npos, const int32_t *__restrict__ rows,
+    const uint32_t *__restrict__ blkmask, int n_blk, const float *__restrict__ residual,
+    float *__restrict__ out) {
+  constexpr int LDA = CT + 4;  // +4 dwords: conflict-free ds_read_b128 of 32 rows
+  constexpr int NT = COUT / 32;
+  constexpr int CP = CT * NCT;
+  constexpr int LPR = CT / 4;    // lanes per gathered row (16 B each)
+  constexpr int RPI = 64 / LPR;  // rows per wave-wide load instruction
+  constexpr int NIT = 32 / RPI;
+  __shared__ __attribute__((aligned(16))) float smem[WPB * 32 * LDA];
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int blk = blockIdx.x * WPB + wave;
+  if (blk >= n_blk) return;  // waves are independent: no barrier below
+  float *As = smem + wave * 32 * LDA;
+  const int r = lane & 31, h = lane >> 5;
+  const int grow = lane / LPR, gc4 = lane % LPR;
+
+  uint32_t mask = blkmask[blk];
+  const int rowid = rows[blk * 32 + r];
+  f32x16 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[nt][i] = 0.f;
+
+  const bool vec = (cin == CP);
+  while (mask) {
+    const int k = __builtin_ctz(mask);
+    mask &= mask - 1;
+    const int src = nbrT[(size_t)k * npos + blk * 32 + r];
+#pragma unroll 1
+    for (int ct = 0; ct < NCT; ct++) {
+      // ---- gather 32 input rows (this Cin tile) into the wave's LDS tile ----
+      if (vec) {
+        f32x4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+          const int s = __shfl(src, it * RPI + grow, 64);
+          f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          v[it] = z;
+          if (s >= 0) v[it] = *(const f32x4 *)(in + (size_t)s * cin + ct * CT + gc4 * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++)
+          *(f32x4 *)(As + (it * RPI + grow) * LDA + gc4 * 4) = v[it];
+      } else {
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+          const int s = __shfl(src, it * RPI + grow, 64);
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (s >= 0) {
+            const float *p = in + (size_t)s * cin;
+            const int c = ct * CT + gc4 * 4;
+            if (c + 0 < cin) v[0] = p[c + 0];
+            if (c + 1 < cin) v[1] = p[c + 1];
+            if (c + 2 < cin) v[2] = p[c + 2];
+            if (c + 3 < cin) v[3] = p[c + 3];
+          }
+          *(f32x4 *)(As + (it * RPI + grow) * LDA + gc4 * 4) = v;
+        }
+      }
+      wave_lds_sync();
+      // ---- 32 x COUT += A[32 x CT] * W[k][CT x COUT] on the matrix cores ----
+      const float *wk = wp + ((size_t)(k * (CP / 4) + ct * (CT / 4)) * COUT) * 4;
+#pragma unroll 2
+      for (int q = 0; q < CT / 8; q++) {
+        const f32x4 a = *(const f32x4 *)(As + r * LDA + q * 8 + h * 4);
+        f32x4 b[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+          b[nt] = *(const f32x4 *)(wk + ((size_t)(2 * q + h) * COUT + nt * 32 + r) * 4);
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[nt][0], acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[nt][1], acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[nt][2], acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[nt][3], acc[nt], 0, 0, 0);
+        }
+      }
+      wave_lds_sync();
+    }
+  }
+  // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
+#pragma unroll
+  for (int reg = 0; reg < 16; reg++) {
+    const int row_in = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    const int orow = __shfl(rowid, row_in, 64);
+    if (orow < 0) continue;
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+      const size_t o = (size_t)orow * COUT + nt * 32 + r;
+      float v = acc[nt][reg];
+      if (residual) v += residual[o];
+      out[o] = v;
+    }
+  }
+}
+
+template <int CT, int NCT, int COUT, int WPB>
+static int launch_t(const Plan &p, const float *in, int cin, const float *wp, const float *residual,
+                    float *out, hipStream_t s) {
+  dim3 grid((p.n_blk + WPB - 1) / WPB);
+  hipLaunchKernelGGL((k_conv<CT, NCT, COUT, WPB>), grid, dim3(WPB * 64), 0, s, in, cin, wp, p.nbrT,
+                     p.n_blk * 32, p.rows, p.blkmask, p.n_blk, residual, out);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+template <int CT, int NCT, int WPB>
+static int launch_c(const Plan &p, const float *in, int cin, const float *wp, int cout,
+                    const float *residual, float *out, hipStream_t s) {
+  switch (cout) {
+    case 32: return launch_t<CT, NCT, 32, WPB>(p, in, cin, wp, residual, out, s);
+    case 64: return launch_t<CT, NCT, 64, WPB>(p, in, cin, wp, residual, out, s);
+    case 128: return launch_t<CT, NCT, 128, WPB>(p, in, cin, wp, residual, out, s);
+    case 256: return launch_t<CT, NCT, 256, WPB>(p, in, cin, wp, residual, out, s);
+  }
+  set_error("convolution: Cout=%d not supported (32, 64, 128, 256)", cout);
+  return D3D_ERR_UNSUPPORTED;
+}
+
+int launch_conv(const Plan &p, const float *in, int cin, const float *packed_w, int cout,
+                const float *residual, float *out, hipStream_t s) {
+  if (p.n_rows == 0) return D3D_OK;
+  D3D_REQUIRE(in && packed_w && out, "convolution: null pointer");
+  switch (padded_cin(cin)) {
+    case 16: return launch_c<16, 1, 4>(p, in, cin, packed_w, cout, residual, out, s);
+    case 32: return launch_c<32, 1, 4>(p, in, cin, packed_w, cout, residual, out, s);
+    case 64: return launch_c<64, 1, 4>(p, in, cin, packed_w, cout, residual, out, s);
+    case 128: return launch_c<128, 1, 2>(p, in, cin, packed_w, cout, residual, out, s);
+    case 256: return launch_c<128, 2, 2>(p, in, cin, packed_w, cout, residual, out, s);
+  }
+  set_error("convolution: Cin=%d not supported (<= 256)", cin);
+  return D3D_ERR_UNSUPPORTED;
+}
+
+}  // namespace d3d
+
+using namespace d3d;
+
+extern "C" {
+
+size_t d3d_packed_weight_floats(int fv, int cin, int cout) {
+  int cp = padded_cin(cin);
+  if (cp < 0 || fv <= 0 || cout <= 0) return 0;
+  return (size_t)fv * cp * cout;
+}
+
+int d3d_pack_conv_weight(const float *w, int fv, int cin, int cout, float *packed, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  int cp = padded_cin(cin);
+  D3D_REQUIRE(w && packed && fv > 0 && cout > 0 && cp > 0, "pack_conv_weight: bad arguments (Cin=%d)", cin);
+  long total = (long)fv * cp * cout;
+  hipLaunchKernelGGL(k_pack_weight, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, fv, cin, cout, cp, packed);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+int d3d_subm_conv_forward(d3d_meta *m, const int *size, const int *filt, const float *in, int cin,
+                          const float *packed_w, int cout, const float *residual, float *out,
+                          void *stream, double *macs_host) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(m && size && filt, "null argument");
+  int rc = d3d_subm_prepare(m, size, filt, stream, nullptr);
+  if (rc) return rc;
+  const Plan *p = find_plan(m, 0, size, filt, nullptr);
+  if (macs_host) *macs_host = (double)p->n_rules * cin * cout;
+  return launch_conv(*p, in, cin, packed_w, cout, residual, out, s);
+}
+
+int d3d_conv_forward(d3d_meta *m, const int *in_size, const int *out_size, const int *filt,
+                     const int *stride, const float *in, int cin, const float *packed_w, int cout,
+                     float *out, void *stream, double *macs_host) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(m && in_size && out_size && filt && stride, "null argument");
+  int rc = d3d_conv_prepare(m, in_size, out_size, filt, stride, stream, nullptr, nullptr);
+  if (rc) return rc;
+  const Plan *p = find_plan(m, 1, in_size, filt, stride);
+  if (macs_host) *macs_host = (double)p->n_rules * cin * cout;
+  return launch_conv(*p, in, cin, packed_w, cout, nullptr, out, s);
+}
+
+// Deconvolution: in = coarse features, out = fine features; reuses the strided rulebook of the
+// matching convolution with the roles swapped (SCN/CPU/Deconvolution.cpp:17,33-37).
+int d3d_deconv_forward(d3d_meta *m, const int *in_size, const int *out_size, const int *filt,
+                       const int *stride, const float *in, int cin, const float *packed_w, int cout,
+                       const float *residual, float *out, void *stream, double *macs_host) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(m && in_size && out_size && filt && stride, "null argument");
+  const Plan *p = nullptr;
+  int rc = get_deconv_plan(m, out_size, filt, stride, s, &p);
+  if (rc) return rc;
+  if (macs_host) *macs_host = (double)p->n_rules * cin * cout;
+  return launch_conv(*p, in, cin, packed_w, cout, residual, out, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,161 @@
+// Internal declarations shared by the translation units of libd3d_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <array>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <vector>
+
+#include "../../include/d3d_hip.h"
+
+namespace d3d {
+
+void set_error(const char *fmt, ...);
+
+#define D3D_HIP_CHECK(expr)                                                          \
+  do {                                                                               \
+    hipError_t _e = (expr);                                                          \
+    if (_e != hipSuccess) {                                                          \
+      d3d::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return D3D_ERR_HIP;                                                            \
+    }                                                                                \
+  } while (0)
+
+#define D3D_REQUIRE(cond, ...)        \
+  do {                                \
+    if (!(cond)) {                    \
+      d3d::set_error(__VA_ARGS__);    \
+      return D3D_ERR_ARG;             \
+    }                                 \
+  } while (0)
+
+#define D3D_LAUNCH_CHECK() D3D_HIP_CHECK(hipGetLastError())
+
+// One HBM slab, bump-allocated; everything a scene needs (hash grids, rulebooks, scratch)
+// lives here and is dropped by d3d_meta_clear.  Stream-ordered use on ONE stream.
+struct Arena {
+  char *base = nullptr;
+  size_t cap = 0, used = 0;
+  void *alloc(size_t bytes) {
+    size_t off = (used + 255) & ~size_t(255);
+    if (off + bytes > cap) return nullptr;
+    used = off + bytes;
+    return base + off;
+  }
+  template <typename T>
+  T *get(size_t count) {
+    return static_cast<T *>(alloc(count * sizeof(T)));
+  }
+};
+
+#define D3D_ALLOC(ptr, T, arena, count)                                                \
+  T *ptr = (arena).get<T>(count);                                                      \
+  if (!ptr) {                                                                          \
+    d3d::set_error("metadata arena exhausted (%zu of %zu bytes used, need %zu more)", \
+                   (arena).used, (arena).cap, (size_t)(count) * sizeof(T));            \
+    return D3D_ERR_NOMEM;                                                              \
+  }
+
+static constexpr uint64_t kEmptyKey = ~uint64_t(0);
+
+// Sparse grid of one spatial size: open-addressing hash (key -> site id) + site coordinates.
+struct Grid {
+  int size[3] = {0, 0, 0};
+  int n = 0;        // active sites
+  int cap = 0;      // hash capacity (power of two)
+  uint64_t *keys = nullptr;
+  int32_t *vals = nullptr;
+  int32_t *loc = nullptr;  // [n,4] x,y,z,b
+};
+
+// Output-stationary rulebook ("plan") of one convolution:
+//   rows   [n_blk*32]      output row of every position, sorted by neighbour mask, -1 padded
+//   nbrT   [K][n_blk*32]   input row feeding position p through filter offset k, or -1
+//   blkmask[n_blk]         OR over the block's 32 positions of their offset bit masks
+struct Plan {
+  int K = 0;
+  int n_rows = 0;
+  int n_blk = 0;
+  long n_rules = 0;
+  int32_t *rows = nullptr;
+  int32_t *nbrT = nullptr;
+  uint32_t *blkmask = nullptr;
+};
+
+typedef std::array<int, 3> Size3;
+typedef std::array<int, 10> PlanKey;  // kind, in_size[3], filter[3], stride[3]
+
+struct StridedRaw {  // kept so that the deconvolution plan can be finalised lazily
+  int32_t *nbr_dec = nullptr;  // [n_in][K]
+  int n_in = 0;
+  Size3 out_size;
+};
+
+}  // namespace d3d
+
+struct d3d_meta {
+  d3d::Arena arena;
+  std::map<d3d::Size3, d3d::Grid> grids;
+  std::map<d3d::PlanKey, d3d::Plan> plans;
+  std::map<d3d::PlanKey, d3d::StridedRaw> strided_raw;
+  // input layer
+  int in_n = 0, in_mode = 0, in_active = 0;
+  int32_t *in_off = nullptr, *in_idx = nullptr;
+  // pinned host words for size read-backs
+  long *host_words = nullptr;
+};
+
+namespace d3d {
+
+// utilities implemented in grid.hip
+int scan_exclusive_i32(const int32_t *in, int32_t *out, int n, int32_t *total_dev, Arena &scratch,
+                       hipStream_t s);
+int sort_pairs_u32(const uint32_t *keys_in, uint32_t *keys_out, const int32_t *vals_in,
+                   int32_t *vals_out, int n, int end_bit, Arena &scratch, hipStream_t s);
+int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan, hipStream_t s);
+const Plan *find_plan(d3d_meta *m, int kind, const int *in_size, const int *filt, const int *stride);
+int get_deconv_plan(d3d_meta *m, const int *fine_size, const int *filt, const int *stride,
+                    hipStream_t s, const Plan **out);
+
+// conv.hip
+int launch_conv(const Plan &p, const float *in, int cin, const float *packed_w, int cout,
+                const float *residual, float *out, hipStream_t s);
+
+__device__ __forceinline__ uint64_t pack_key(int b, int x, int y, int z) {
+  return ((uint64_t)(uint16_t)b << 48) | ((uint64_t)(uint16_t)x << 32) |
+         ((uint64_t)(uint16_t)y << 16) | (uint64_t)(uint16_t)z;
+}
+__device__ __forceinline__ uint32_t hash_key(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdULL;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ULL;
+  k ^= k >> 33;
+  return (uint32_t)k;
+}
+// returns the slot holding `key` (inserting it if absent)
+__device__ __forceinline__ int hash_insert(uint64_t *keys, int cap, uint64_t key) {
+  uint32_t slot = hash_key(key) & (uint32_t)(cap - 1);
+  while (true) {
+    unsigned long long prev = atomicCAS((unsigned long long *)&keys[slot],
+                                        (unsigned long long)kEmptyKey, (unsigned long long)key);
+    if (prev == kEmptyKey || prev == key) return (int)slot;
+    slot = (slot + 1) & (uint32_t)(cap - 1);
+  }
+}
+// returns the site id stored for `key`, or -1
+__device__ __forceinline__ int hash_find(const uint64_t *__restrict__ keys,
+                                         const int32_t *__restrict__ vals, int cap, uint64_t key) {
+  uint32_t slot = hash_key(key) & (uint32_t)(cap - 1);
+  while (true) {
+    uint64_t k = keys[slot];
+    if (k == key) return vals[slot];
+    if (k == kEmptyKey) return -1;
+    slot = (slot + 1) & (uint32_t)(cap - 1);
+  }
+}
+
+}  // namespace d3d

@@ -1,0 +1,881 @@
+// Sparse-grid metadata on the device: voxel hash-scatter (input layer), strided-conv output
+// grids, submanifold / strided rulebooks ("plans"), spatial locations, sparse->dense.
+// Replaces the single-threaded CPU rule builders of SCN/Metadata/* (see include/d3d_hip.h).
+#include <climits>
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "d3d_internal.h"
+
+namespace d3d {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------------
+// Exclusive scan of int32: wave64 shuffle scan -> block scan -> block-sum scan -> add.
+static constexpr int kScanThreads = 256;
+static constexpr int kScanItems = 8;
+static constexpr int kScanTile = kScanThreads * kScanItems;
+
+__device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_tiles(const int32_t *__restrict__ in,
+                                                             int32_t *__restrict__ out, int n,
+                                                             int32_t *__restrict__ tile_sums) {
+  __shared__ int wave_tot[kScanThreads / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long base = (long)blockIdx.x * kScanTile + (long)tid * kScanItems;
+  int v[kScanItems];
+  int sum = 0;
+#pragma unroll
+  for (int i = 0; i < kScanItems; i++) {
+    v[i] = (base + i < n) ? in[base + i] : 0;
+    sum += v[i];
+  }
+  int incl = wave_inclusive_scan(sum, lane);
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  int wave_off = 0;
+  for (int w = 0; w < wave; w++) wave_off += wave_tot[w];
+  int run = wave_off + incl - sum;
+#pragma unroll
+  for (int i = 0; i < kScanItems; i++) {
+    if (base + i < n) out[base + i] = run;
+    run += v[i];
+  }
+  if (tid == kScanThreads - 1) tile_sums[blockIdx.x] = run;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_sums(int32_t *__restrict__ sums, int nb,
+                                                    int32_t *__restrict__ total) {
+  __shared__ int wave_tot[16];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += 1024) {
+    int i = base + tid;
+    int v = i < nb ? sums[i] : 0;
+    int incl = wave_inclusive_scan(v, lane);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int off = carry_s;
+    for (int w = 0; w < wave; w++) off += wave_tot[w];
+    if (i < nb) sums[i] = off + incl - v;
+    __syncthreads();
+    if (tid == 1023) carry_s = off + incl;
+    __syncthreads();
+  }
+  if (tid == 0 && total) *total = carry_s;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_add(int32_t *__restrict__ out, int n,
+                                                           const int32_t *__restrict__ sums) {
+  const long base = (long)blockIdx.x * kScanTile + (long)threadIdx.x * kScanItems;
+  const int add = sums[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < kScanItems; i++)
+    if (base + i < n) out[base + i] += add;
+}
+
+int scan_exclusive_i32(const int32_t *in, int32_t *out, int n, int32_t *total_dev, Arena &scratch,
+                       hipStream_t s) {
+  if (n <= 0) {
+    if (total_dev) D3D_HIP_CHECK(hipMemsetAsync(total_dev, 0, sizeof(int32_t), s));
+    return D3D_OK;
+  }
+  int nb = (n + kScanTile - 1) / kScanTile;
+  D3D_ALLOC(sums, int32_t, scratch, nb);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(nb), dim3(kScanThreads), 0, s, in, out, n, sums);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, sums, nb, total_dev);
+  hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(kScanThreads), 0, s, out, n, sums);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+int sort_pairs_u32(const uint32_t *keys_in, uint32_t *keys_out, const int32_t *vals_in,
+                   int32_t *vals_out, int n, int end_bit, Arena &scratch, hipStream_t s) {
+  if (n <= 0) return D3D_OK;
+  size_t tmp_bytes = 0;
+  D3D_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out,
+                                          (size_t)n, 0u, (unsigned)end_bit, s));
+  D3D_ALLOC(tmp, char, scratch, tmp_bytes);
+  D3D_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out,
+                                          (size_t)n, 0u, (unsigned)end_bit, s));
+  return D3D_OK;
+}
+
+__global__ void k_iota(int32_t *p, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+
+struct CapGuard {  // temporarily shrinks the arena so that a raw table can sit at its far end
+  Arena &a;
+  size_t save;
+  CapGuard(Arena &a_, size_t new_cap) : a(a_), save(a_.cap) { a.cap = new_cap; }
+  ~CapGuard() { a.cap = save; }
+};
+static inline int next_pow2(long v) {
+  long c = 1024;
+  while (c < v) c <<= 1;
+  return (int)c;
+}
+static inline dim3 grid1d(long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+
+// ------------------------------------------------------------------------------------------
+// a2. Input layer: hash insert + first-occurrence numbering (IOLayersRules.h:72-95).
+__global__ void k_insert_points(const int64_t *__restrict__ coords, int n, int ncols,
+                                uint64_t *keys, int32_t *first, int cap, int32_t *pslot) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t *c = coords + (size_t)i * ncols;
+  int b = ncols == 4 ? (int)c[3] : 0;
+  int slot = hash_insert(keys, cap, pack_key(b, (int)c[0], (int)c[1], (int)c[2]));
+  atomicMin(&first[slot], i);
+  pslot[i] = slot;
+}
+__global__ void k_flag_first(const int32_t *__restrict__ pslot, const int32_t *__restrict__ first,
+                             int n, int32_t *flag) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = (pslot[i] >= 0 && first[pslot[i]] == i) ? 1 : 0;
+}
+__global__ void k_assign_input_sites(const int64_t *__restrict__ coords, int n, int ncols,
+                                     const int32_t *__restrict__ pslot,
+                                     const int32_t *__restrict__ flag,
+                                     const int32_t *__restrict__ rank, int32_t *vals, int32_t *loc) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !flag[i]) return;
+  int id = rank[i];
+  vals[pslot[i]] = id;
+  const int64_t *c = coords + (size_t)i * ncols;
+  loc[id * 4 + 0] = (int)c[0];
+  loc[id * 4 + 1] = (int)c[1];
+  loc[id * 4 + 2] = (int)c[2];
+  loc[id * 4 + 3] = ncols == 4 ? (int)c[3] : 0;
+}
+__global__ void k_point_site(const int32_t *__restrict__ pslot, const int32_t *__restrict__ vals,
+                             int n, uint32_t *psite, int32_t *cnt) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int s = vals[pslot[i]];
+  psite[i] = (uint32_t)s;
+  atomicAdd(&cnt[s], 1);
+}
+// a3. CPU/IOLayers.cpp:11-29: out[row] += mult * in[idx] in input order.
+__global__ void k_input_forward(const float *__restrict__ in, int planes,
+                                const int32_t *__restrict__ off, const int32_t *__restrict__ idx,
+                                int n_active, int average, float *__restrict__ out) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)n_active * planes) return;
+  int row = (int)(t / planes), c = (int)(t % planes);
+  int b = off[row], e = off[row + 1];
+  int cnt = e - b;
+  float mult = (average && cnt > 0) ? (float)1 / cnt : (float)1;
+  float acc = 0.f;
+  for (int j = b; j < e; j++) acc += mult * in[(size_t)idx[j] * planes + c];
+  out[t] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// a5. Strided convolution: output grid + raw neighbour tables (ConvolutionRules.h:12-34).
+struct ConvGeom {
+  int filt[3], stride[3], out_size[3];
+  int max_out;
+};
+__device__ __forceinline__ bool conv_entry(const ConvGeom &g, const int32_t *p, int j, int *o,
+                                           int *off) {
+  int lb[3], cnt[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    int t = p[d] - g.filt[d] + g.stride[d];
+    int l = t < 0 ? 0 : t / g.stride[d];          // max(0, (in - size + stride) / stride)
+    int u = min(g.out_size[d] - 1, p[d] / g.stride[d]);
+    lb[d] = l;
+    cnt[d] = u - l + 1;
+    if (cnt[d] <= 0) return false;
+  }
+  if (j >= cnt[0] * cnt[1] * cnt[2]) return false;
+  int jz = j % cnt[2], jy = (j / cnt[2]) % cnt[1], jx = j / (cnt[2] * cnt[1]);
+  o[0] = lb[0] + jx;
+  o[1] = lb[1] + jy;
+  o[2] = lb[2] + jz;
+  *off = ((p[0] - o[0] * g.stride[0]) * g.filt[1] + (p[1] - o[1] * g.stride[1])) * g.filt[2] +
+         (p[2] - o[2] * g.stride[2]);
+  return true;
+}
+__global__ void k_conv_insert(const int32_t *__restrict__ loc, long n_entries, ConvGeom g,
+                              uint64_t *keys, int32_t *first, int cap, int32_t *eslot) {
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_entries) return;
+  int i = (int)(e / g.max_out), j = (int)(e % g.max_out);
+  const int32_t *p = loc + (size_t)i * 4;
+  int o[3], off;
+  if (!conv_entry(g, p, j, o, &off)) {
+    eslot[e] = -1;
+    return;
+  }
+  int slot = hash_insert(keys, cap, pack_key(p[3], o[0], o[1], o[2]));
+  atomicMin(&first[slot], (int)e);
+  eslot[e] = slot;
+}
+__global__ void k_conv_assign(const int32_t *__restrict__ loc, long n_entries, ConvGeom g,
+                              const int32_t *__restrict__ eslot, const int32_t *__restrict__ flag,
+                              const int32_t *__restrict__ rank, int32_t *vals, int32_t *loc_out) {
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_entries || !flag[e]) return;
+  int i = (int)(e / g.max_out), j = (int)(e % g.max_out);
+  const int32_t *p = loc + (size_t)i * 4;
+  int o[3], off;
+  conv_entry(g, p, j, o, &off);
+  int id = rank[e];
+  vals[eslot[e]] = id;
+  loc_out[id * 4 + 0] = o[0];
+  loc_out[id * 4 + 1] = o[1];
+  loc_out[id * 4 + 2] = o[2];
+  loc_out[id * 4 + 3] = p[3];
+}
+__global__ void k_conv_fill(const int32_t *__restrict__ loc, long n_entries, ConvGeom g, int K,
+                            const int32_t *__restrict__ eslot, const int32_t *__restrict__ vals,
+                            int32_t *nbr_fwd, int32_t *nbr_dec) {
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_entries || eslot[e] < 0) return;
+  int i = (int)(e / g.max_out), j = (int)(e % g.max_out);
+  const int32_t *p = loc + (size_t)i * 4;
+  int o[3], off;
+  conv_entry(g, p, j, o, &off);
+  int oid = vals[eslot[e]];
+  nbr_fwd[(size_t)oid * K + off] = i;
+  nbr_dec[(size_t)i * K + off] = oid;
+}
+
+// a4. Submanifold neighbour probes (SubmanifoldConvolutionRules.h:13-45).
+__global__ void k_subm_nbr(const int32_t *__restrict__ loc, int n, int fx, int fy, int fz,
+                           const uint64_t *__restrict__ keys, const int32_t *__restrict__ vals,
+                           int cap, int32_t *__restrict__ nbr) {
+  const int K = fx * fy * fz;
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)n * K) return;
+  int i = (int)(t / K), k = (int)(t % K);
+  int dz = k % fz, dy = (k / fz) % fy, dx = k / (fz * fy);
+  const int32_t *p = loc + (size_t)i * 4;
+  int x = p[0] - fx / 2 + dx, y = p[1] - fy / 2 + dy, z = p[2] - fz / 2 + dz;
+  int v = -1;
+  if (x >= 0 && y >= 0 && z >= 0) v = hash_find(keys, vals, cap, pack_key(p[3], x, y, z));
+  nbr[t] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Plan finalisation: per-row offset masks, sort rows by mask, transpose, block masks.
+__global__ void k_row_mask(const int32_t *__restrict__ nbr, int n, int K, uint32_t *mask,
+                           unsigned long long *n_rules) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t m = 0;
+  if (i < n)
+    for (int k = 0; k < K; k++) m |= (nbr[(size_t)i * K + k] >= 0 ? 1u : 0u) << k;
+  if (i < n) mask[i] = m;
+  // wave-level popcount reduction, one atomic per wave
+  int c = __popc(m);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(n_rules, (unsigned long long)c);
+}
+__global__ void k_plan_transpose(const int32_t *__restrict__ nbr, const int32_t *__restrict__ rows,
+                                 int npos, int K, int32_t *__restrict__ nbrT) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)npos * K) return;
+  int k = (int)(t / npos), p = (int)(t % npos);
+  int r = rows[p];
+  nbrT[t] = r >= 0 ? nbr[(size_t)r * K + k] : -1;
+}
+// one wave per block of 32 positions: wave64 ballot, low half tests offset k, high half k+1
+__global__ void k_blk_mask(const int32_t *__restrict__ nbrT, int npos, int K, int n_blk,
+                           uint32_t *__restrict__ blkmask) {
+  int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int lane = threadIdx.x & 63;
+  if (wave >= n_blk) return;
+  uint32_t m = 0;
+  for (int k = 0; k < K; k += 2) {
+    int kk = k + (lane >> 5);
+    bool hit = kk < K && nbrT[(size_t)kk * npos + wave * 32 + (lane & 31)] >= 0;
+    unsigned long long bal = __ballot(hit);
+    if (bal & 0xffffffffull) m |= 1u << k;
+    if (bal >> 32) m |= 1u << (k + 1);
+  }
+  if (lane == 0) blkmask[wave] = m;
+}
+__global__ void k_pad_rows(int32_t *rows, int n, int npos) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x + n;
+  if (i < npos) rows[i] = -1;
+}
+
+int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan, hipStream_t s) {
+  D3D_REQUIRE(K >= 1 && K <= 32, "filter volume %d not supported (1..32)", K);
+  Arena &A = m->arena;
+  plan.K = K;
+  plan.n_rows = n_rows;
+  plan.n_blk = (n_rows + 31) / 32;
+  const int npos = plan.n_blk * 32;
+  D3D_ALLOC(rows, int32_t, A, (size_t)npos + 1);
+  D3D_ALLOC(nbrT, int32_t, A, (size_t)npos * K + 1);
+  D3D_ALLOC(blkmask, uint32_t, A, (size_t)plan.n_blk + 1);
+  D3D_ALLOC(cnt, unsigned long long, A, 1);
+  plan.rows = rows;
+  plan.nbrT = nbrT;
+  plan.blkmask = blkmask;
+  plan.n_rules = 0;
+  if (n_rows == 0) return D3D_OK;
+  size_t mark = A.used;
+  D3D_ALLOC(mask, uint32_t, A, n_rows);
+  D3D_ALLOC(mask_sorted, uint32_t, A, n_rows);
+  D3D_ALLOC(iota, int32_t, A, n_rows);
+  D3D_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), s));
+  hipLaunchKernelGGL(k_row_mask, grid1d(n_rows), dim3(256), 0, s, nbr, n_rows, K, mask, cnt);
+  hipLaunchKernelGGL(k_iota, grid1d(n_rows), dim3(256), 0, s, iota, n_rows);
+  int rc = sort_pairs_u32(mask, mask_sorted, iota, rows, n_rows, K, A, s);
+  if (rc) return rc;
+  if (npos > n_rows) hipLaunchKernelGGL(k_pad_rows, grid1d(npos - n_rows), dim3(256), 0, s, rows, n_rows, npos);
+  hipLaunchKernelGGL(k_plan_transpose, grid1d((long)npos * K), dim3(256), 0, s, nbr, rows, npos, K, nbrT);
+  hipLaunchKernelGGL(k_blk_mask, grid1d((long)plan.n_blk * 64), dim3(256), 0, s, nbrT, npos, K,
+                     plan.n_blk, blkmask);
+  D3D_LAUNCH_CHECK();
+  D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[0], cnt, sizeof(long), hipMemcpyDeviceToHost, s));
+  D3D_HIP_CHECK(hipStreamSynchronize(s));
+  plan.n_rules = m->host_words[0];
+  A.used = mark;  // scratch released (stream-ordered reuse)
+  return D3D_OK;
+}
+
+static PlanKey make_key(int kind, const int *in_size, const int *filt, const int *stride) {
+  PlanKey k;
+  k[0] = kind;
+  for (int d = 0; d < 3; d++) {
+    k[1 + d] = in_size[d];
+    k[4 + d] = filt[d];
+    k[7 + d] = stride ? stride[d] : 0;
+  }
+  return k;
+}
+const Plan *find_plan(d3d_meta *m, int kind, const int *in_size, const int *filt, const int *stride) {
+  auto it = m->plans.find(make_key(kind, in_size, filt, stride));
+  return it == m->plans.end() ? nullptr : &it->second;
+}
+
+int get_deconv_plan(d3d_meta *m, const int *fine_size, const int *filt, const int *stride,
+                    hipStream_t s, const Plan **out) {
+  PlanKey key = make_key(2, fine_size, filt, stride);
+  auto it = m->plans.find(key);
+  if (it == m->plans.end()) {
+    auto raw = m->strided_raw.find(make_key(1, fine_size, filt, stride));
+    if (raw == m->strided_raw.end()) {
+      set_error("deconvolution: no strided rulebook for this (size, filter, stride); run the "
+                "matching convolution (d3d_conv_prepare) first");
+      return D3D_ERR_STATE;
+    }
+    Plan p;
+    int K = filt[0] * filt[1] * filt[2];
+    int rc = finalize_plan(m, raw->second.nbr_dec, raw->second.n_in, K, p, s);
+    if (rc) return rc;
+    it = m->plans.emplace(key, p).first;
+  }
+  *out = &it->second;
+  return D3D_OK;
+}
+
+__global__ void k_locations(const int32_t *__restrict__ loc, int n, int64_t *__restrict__ out) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n * 4) out[t] = loc[t];
+}
+__global__ void k_sparse_to_dense(const float *__restrict__ in, int planes,
+                                  const int32_t *__restrict__ loc, int n, int sx, int sy, int sz,
+                                  float *__restrict__ out) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)n * planes) return;
+  // consecutive threads -> consecutive sites (coalesced-ish writes along z), plane-major loop
+  int i = (int)(t % n), c = (int)(t / n);
+  const int32_t *p = loc + (size_t)i * 4;
+  size_t vol = (size_t)sx * sy * sz;
+  size_t off = ((size_t)p[0] * sy + p[1]) * sz + p[2];
+  out[((size_t)p[3] * planes + c) * vol + off] = in[(size_t)i * planes + c];
+}
+__global__ void k_export_plan(const int32_t *__restrict__ nbrT, const int32_t *__restrict__ rows,
+                              int npos, int K, int swap, int32_t *triples, long capacity,
+                              unsigned long long *count) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)npos * K) return;
+  int k = (int)(t / npos), p = (int)(t % npos);
+  int src = nbrT[t];
+  if (src < 0) return;
+  unsigned long long w = atomicAdd(count, 1ull);
+  if ((long)w < capacity) {
+    triples[w * 3 + 0] = swap ? rows[p] : src;
+    triples[w * 3 + 1] = swap ? src : rows[p];
+    triples[w * 3 + 2] = k;
+  }
+}
+__global__ void k_export_input(const int32_t *a, int32_t *b, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) b[i] = a[i];
+}
+
+// a1 -------------------------------------------------------------------------------------
+__global__ void k_vox_min(const float *__restrict__ pcl, int n, int nfeat, double scale,
+                          unsigned long long *mins /*3, ordered-uint encoded*/) {
+  // per-axis min of (double)x*scale; doubles mapped to order-preserving uint64 for atomicMin
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double v[3] = {1e300, 1e300, 1e300};
+  if (i < n)
+    for (int d = 0; d < 3; d++) v[d] = (double)pcl[(size_t)i * nfeat + d] * scale;
+  for (int d = 0; d < 3; d++) {
+    double x = v[d];
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) x = fmin(x, __shfl_xor(x, s, 64));
+    if ((threadIdx.x & 63) == 0) {
+      unsigned long long u = (unsigned long long)__double_as_longlong(x);
+      u = (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+      atomicMin(&mins[d], u);
+    }
+  }
+}
+__device__ __forceinline__ double decode_ordered(unsigned long long u) {
+  u = (u >> 63) ? (u & 0x7fffffffffffffffull) : ~u;
+  return __longlong_as_double((long long)u);
+}
+__global__ void k_vox_flag(const float *__restrict__ pcl, int n, int nfeat, double scale,
+                           const unsigned long long *mins, int fx, int fy, int fz, int32_t *flag) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int full[3] = {fx, fy, fz};
+  bool ok = true;
+  for (int d = 0; d < 3; d++) {
+    double a = (double)pcl[(size_t)i * nfeat + d] * scale + (-decode_ordered(mins[d]));
+    ok = ok && (a >= 0) && (a < (double)full[d]);
+  }
+  flag[i] = ok ? 1 : 0;
+}
+__global__ void k_vox_write(const float *__restrict__ pcl, int n, int nfeat, double scale,
+                            const unsigned long long *mins, const int32_t *__restrict__ flag,
+                            const int32_t *__restrict__ rank, int64_t *coords, float *feats) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !flag[i]) return;
+  int o = rank[i];
+  for (int d = 0; d < 3; d++) {
+    double a = (double)pcl[(size_t)i * nfeat + d] * scale + (-decode_ordered(mins[d]));
+    coords[(size_t)o * 3 + d] = (int64_t)a;                  // trunc, suncg_dataset.py:173
+    feats[(size_t)o * nfeat + d] = (float)(a / scale);        // :149
+  }
+  for (int c = 3; c < nfeat; c++) feats[(size_t)o * nfeat + c] = pcl[(size_t)i * nfeat + c];
+}
+
+}  // namespace d3d
+
+using namespace d3d;
+
+extern "C" {
+
+const char *d3d_last_error(void) { return d3d::g_err; }
+int d3d_abi_version(void) { return 1; }
+
+int d3d_meta_create(d3d_meta **out, size_t arena_bytes) {
+  D3D_REQUIRE(out && arena_bytes >= (1u << 20), "d3d_meta_create: bad arguments");
+  d3d_meta *m = new d3d_meta();
+  hipError_t e = hipMalloc((void **)&m->arena.base, arena_bytes);
+  if (e != hipSuccess) {
+    set_error("hipMalloc(%zu) failed: %s", arena_bytes, hipGetErrorString(e));
+    delete m;
+    return D3D_ERR_HIP;
+  }
+  m->arena.cap = arena_bytes;
+  e = hipHostMalloc((void **)&m->host_words, 16 * sizeof(long), hipHostMallocDefault);
+  if (e != hipSuccess) {
+    set_error("hipHostMalloc failed: %s", hipGetErrorString(e));
+    (void)hipFree(m->arena.base);
+    delete m;
+    return D3D_ERR_HIP;
+  }
+  *out = m;
+  return D3D_OK;
+}
+int d3d_meta_destroy(d3d_meta *m) {
+  if (!m) return D3D_OK;
+  (void)hipFree(m->arena.base);
+  (void)hipHostFree(m->host_words);
+  delete m;
+  return D3D_OK;
+}
+int d3d_meta_clear(d3d_meta *m) {
+  D3D_REQUIRE(m, "null metadata");
+  m->arena.used = 0;
+  m->grids.clear();
+  m->plans.clear();
+  m->strided_raw.clear();
+  m->in_n = m->in_mode = m->in_active = 0;
+  m->in_off = m->in_idx = nullptr;
+  return D3D_OK;
+}
+int d3d_meta_arena_used(d3d_meta *m, size_t *bytes_host) {
+  D3D_REQUIRE(m && bytes_host, "null argument");
+  *bytes_host = m->arena.used;
+  return D3D_OK;
+}
+
+size_t d3d_voxelize_scratch_bytes(int n) {
+  size_t nb = ((size_t)n + kScanTile - 1) / kScanTile;
+  return 256 * 4 + (size_t)n * 8 + nb * 4 + 4096;
+}
+int d3d_voxelize(const float *pcl, int n, int nfeat, double scale, const int *full, int64_t *coords,
+                 float *feats, int *n_kept_host, void *scratch, size_t scratch_bytes, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(pcl && coords && feats && n_kept_host && full && nfeat >= 3 && n >= 0, "d3d_voxelize: bad arguments");
+  D3D_REQUIRE(scratch_bytes >= d3d_voxelize_scratch_bytes(n), "d3d_voxelize: scratch too small");
+  *n_kept_host = 0;
+  if (n == 0) return D3D_OK;
+  Arena A;
+  A.base = (char *)scratch;
+  A.cap = scratch_bytes;
+  D3D_ALLOC(mins, unsigned long long, A, 4);
+  D3D_ALLOC(flag, int32_t, A, n);
+  D3D_ALLOC(rank, int32_t, A, n);
+  D3D_HIP_CHECK(hipMemsetAsync(mins, 0xFF, 4 * sizeof(unsigned long long), s));
+  hipLaunchKernelGGL(k_vox_min, grid1d(n), dim3(256), 0, s, pcl, n, nfeat, scale, mins);
+  hipLaunchKernelGGL(k_vox_flag, grid1d(n), dim3(256), 0, s, pcl, n, nfeat, scale, mins, full[0], full[1], full[2], flag);
+  int rc = scan_exclusive_i32(flag, rank, n, (int32_t *)(mins + 3), A, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_vox_write, grid1d(n), dim3(256), 0, s, pcl, n, nfeat, scale, mins, flag, rank, coords, feats);
+  D3D_LAUNCH_CHECK();
+  int32_t total = 0;
+  D3D_HIP_CHECK(hipMemcpyAsync(&total, mins + 3, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  D3D_HIP_CHECK(hipStreamSynchronize(s));
+  *n_kept_host = total;
+  return D3D_OK;
+}
+
+int d3d_input_layer_build(d3d_meta *m, const int64_t *coords, int n, int ncols, const int *size,
+                          int batch_size, int mode, void *stream, int *n_active_host) {
+  hipStream_t s = (hipStream_t)stream;
+  (void)batch_size;
+  D3D_REQUIRE(m && size && n_active_host, "null argument");
+  D3D_REQUIRE(ncols == 3 || ncols == 4, "coords must be [n,3] or [n,4], got %d columns", ncols);
+  D3D_REQUIRE(mode == 3 || mode == 4, "input layer mode %d not supported (3=sum, 4=mean)", mode);
+  D3D_REQUIRE(n >= 0 && (n == 0 || coords), "bad coords");
+  if (!m->grids.empty()) {
+    set_error("input layer: metadata already holds grids; call d3d_meta_clear first");
+    return D3D_ERR_STATE;
+  }
+  for (int d = 0; d < 3; d++) D3D_REQUIRE(size[d] > 0 && size[d] <= 32768, "spatial size out of range");
+  Arena &A = m->arena;
+  Grid g;
+  for (int d = 0; d < 3; d++) g.size[d] = size[d];
+  g.cap = next_pow2(2L * n);
+  D3D_ALLOC(keys, uint64_t, A, g.cap);
+  D3D_ALLOC(vals, int32_t, A, g.cap);
+  D3D_ALLOC(loc, int32_t, A, (size_t)n * 4 + 4);
+  D3D_ALLOC(in_off, int32_t, A, (size_t)n + 2);
+  D3D_ALLOC(in_idx, int32_t, A, (size_t)n + 1);
+  g.keys = keys;
+  g.vals = vals;
+  g.loc = loc;
+  m->in_n = n;
+  m->in_mode = mode;
+  m->in_off = in_off;
+  m->in_idx = in_idx;
+  D3D_HIP_CHECK(hipMemsetAsync(keys, 0xFF, sizeof(uint64_t) * g.cap, s));
+  D3D_HIP_CHECK(hipMemsetAsync(vals, 0xFF, sizeof(int32_t) * g.cap, s));
+  int n_active = 0;
+  if (n > 0) {
+    size_t mark = A.used;
+    D3D_ALLOC(first, int32_t, A, g.cap);
+    D3D_ALLOC(pslot, int32_t, A, n);
+    D3D_ALLOC(flag, int32_t, A, n);
+    D3D_ALLOC(rank, int32_t, A, n);
+    D3D_ALLOC(total, int32_t, A, 1);
+    D3D_ALLOC(psite, uint32_t, A, n);
+    D3D_ALLOC(psite_sorted, uint32_t, A, n);
+    D3D_ALLOC(iota, int32_t, A, n);
+    D3D_ALLOC(cnt, int32_t, A, (size_t)n + 1);
+    D3D_HIP_CHECK(hipMemsetAsync(first, 0x7F, sizeof(int32_t) * g.cap, s));
+    hipLaunchKernelGGL(k_insert_points, grid1d(n), dim3(256), 0, s, coords, n, ncols, keys, first, g.cap, pslot);
+    hipLaunchKernelGGL(k_flag_first, grid1d(n), dim3(256), 0, s, pslot, first, n, flag);
+    int rc = scan_exclusive_i32(flag, rank, n, total, A, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_assign_input_sites, grid1d(n), dim3(256), 0, s, coords, n, ncols, pslot, flag, rank, vals, loc);
+    D3D_LAUNCH_CHECK();
+    D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[0], total, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    D3D_HIP_CHECK(hipStreamSynchronize(s));
+    n_active = (int)*(int32_t *)&m->host_words[0];
+    // per-site point lists in input order: stable sort of point ids by site id
+    D3D_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int32_t) * ((size_t)n_active + 1), s));
+    hipLaunchKernelGGL(k_point_site, grid1d(n), dim3(256), 0, s, pslot, vals, n, psite, cnt);
+    hipLaunchKernelGGL(k_iota, grid1d(n), dim3(256), 0, s, iota, n);
+    rc = scan_exclusive_i32(cnt, in_off, n_active + 1, nullptr, A, s);
+    if (rc) return rc;
+    int bits = 1;
+    while ((1L << bits) < n_active) bits++;
+    rc = sort_pairs_u32(psite, psite_sorted, iota, in_idx, n, bits, A, s);
+    if (rc) return rc;
+    D3D_LAUNCH_CHECK();
+    A.used = mark;
+  }
+  g.n = n_active;
+  m->in_active = n_active;
+  m->grids[Size3{size[0], size[1], size[2]}] = g;
+  *n_active_host = n_active;
+  return D3D_OK;
+}
+
+int d3d_input_layer_forward(d3d_meta *m, const float *feats, int planes, float *out, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(m && planes > 0, "bad arguments");
+  if (!m->in_off) {
+    set_error("input layer forward before build");
+    return D3D_ERR_STATE;
+  }
+  if (m->in_active == 0) return D3D_OK;
+  D3D_REQUIRE(feats && out, "null feature pointer");
+  hipLaunchKernelGGL(k_input_forward, grid1d((long)m->in_active * planes), dim3(256), 0, s, feats,
+                     planes, m->in_off, m->in_idx, m->in_active, m->in_mode == 4 ? 1 : 0, out);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+int d3d_input_layer_export(d3d_meta *m, int32_t *offsets, int32_t *idx, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(m && offsets && idx, "null argument");
+  if (!m->in_off) {
+    set_error("input layer export before build");
+    return D3D_ERR_STATE;
+  }
+  hipLaunchKernelGGL(k_export_input, grid1d(m->in_active + 1), dim3(256), 0, s, m->in_off, offsets, m->in_active + 1);
+  if (m->in_n) hipLaunchKernelGGL(k_export_input, grid1d(m->in_n), dim3(256), 0, s, m->in_idx, idx, m->in_n);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+static Grid *find_grid(d3d_meta *m, const int *size) {
+  auto it = m->grids.find(Size3{size[0], size[1], size[2]});
+  return it == m->grids.end() ? nullptr : &it->second;
+}
+
+int d3d_get_n_active(d3d_meta *m, const int *size, int *n_host) {
+  D3D_REQUIRE(m && size && n_host, "null argument");
+  Grid *g = find_grid(m, size);
+  if (!g) {
+    set_error("no grid of spatial size [%d,%d,%d]", size[0], size[1], size[2]);
+    return D3D_ERR_STATE;
+  }
+  *n_host = g->n;
+  return D3D_OK;
+}
+
+int d3d_get_spatial_locations(d3d_meta *m, const int *size, int64_t *out, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(m && size, "null argument");
+  Grid *g = find_grid(m, size);
+  if (!g) {
+    set_error("no grid of spatial size [%d,%d,%d]", size[0], size[1], size[2]);
+    return D3D_ERR_STATE;
+  }
+  if (g->n == 0) return D3D_OK;
+  D3D_REQUIRE(out, "null output");
+  hipLaunchKernelGGL(k_locations, grid1d((long)g->n * 4), dim3(256), 0, s, g->loc, g->n, out);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+int d3d_subm_prepare(d3d_meta *m, const int *size, const int *filt, void *stream, long *n_rules_host) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(m && size && filt, "null argument");
+  PlanKey key = make_key(0, size, filt, nullptr);
+  auto it = m->plans.find(key);
+  if (it == m->plans.end()) {
+    Grid *g = find_grid(m, size);
+    if (!g) {
+      set_error("submanifold rulebook: no grid of spatial size [%d,%d,%d]", size[0], size[1], size[2]);
+      return D3D_ERR_STATE;
+    }
+    int K = filt[0] * filt[1] * filt[2];
+    D3D_REQUIRE(filt[0] > 0 && filt[1] > 0 && filt[2] > 0 && K <= 32, "filter volume %d not supported", K);
+    Plan p;
+    Arena &A = m->arena;
+    // raw table lives above the plan's persistent arrays: allocate persistent part first
+    // (finalize_plan), so stage the raw table at the far end of the arena instead.
+    size_t raw_bytes = ((size_t)g->n * K + 1) * sizeof(int32_t);
+    if (A.used + 2 * raw_bytes + (1 << 20) > A.cap) {
+      set_error("metadata arena exhausted while building a submanifold rulebook");
+      return D3D_ERR_NOMEM;
+    }
+    int32_t *nbr = (int32_t *)(A.base + ((A.cap - raw_bytes) & ~size_t(255)));
+    if (g->n)
+      hipLaunchKernelGGL(k_subm_nbr, grid1d((long)g->n * K), dim3(256), 0, s, g->loc, g->n, filt[0],
+                         filt[1], filt[2], g->keys, g->vals, g->cap, nbr);
+    D3D_LAUNCH_CHECK();
+    int rc;
+    {
+      CapGuard guard(A, (A.cap - raw_bytes) & ~size_t(255));
+      rc = finalize_plan(m, nbr, g->n, K, p, s);
+    }
+    if (rc) return rc;
+    it = m->plans.emplace(key, p).first;
+  }
+  if (n_rules_host) *n_rules_host = it->second.n_rules;
+  return D3D_OK;
+}
+
+int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const int *filt,
+                     const int *stride, void *stream, int *n_out_host, long *n_rules_host) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(m && in_size && out_size && filt && stride, "null argument");
+  PlanKey key = make_key(1, in_size, filt, stride);
+  auto it = m->plans.find(key);
+  if (it == m->plans.end()) {
+    Grid *gi = find_grid(m, in_size);
+    if (!gi) {
+      set_error("strided rulebook: no grid of spatial size [%d,%d,%d]", in_size[0], in_size[1], in_size[2]);
+      return D3D_ERR_STATE;
+    }
+    ConvGeom geo;
+    int K = 1, max_out = 1;
+    for (int d = 0; d < 3; d++) {
+      D3D_REQUIRE(filt[d] > 0 && stride[d] > 0 && out_size[d] > 0, "bad filter/stride/size");
+      D3D_REQUIRE((out_size[d] - 1) * stride[d] + filt[d] == in_size[d],
+                  "convolution sizes inconsistent: (out-1)*stride+filter != in (convolution.py:37-38)");
+      geo.filt[d] = filt[d];
+      geo.stride[d] = stride[d];
+      geo.out_size[d] = out_size[d];
+      K *= filt[d];
+      max_out *= (filt[d] + stride[d] - 1) / stride[d];
+    }
+    geo.max_out = max_out;
+    D3D_REQUIRE(K <= 32, "filter volume %d not supported (<= 32)", K);
+    D3D_REQUIRE(max_out <= 8, "each input site may feed at most 8 outputs");
+    if (find_grid(m, out_size)) {
+      set_error("strided rulebook: output grid [%d,%d,%d] already exists", out_size[0], out_size[1], out_size[2]);
+      return D3D_ERR_STATE;
+    }
+    Arena &A = m->arena;
+    const int n_in = gi->n;
+    const long n_entries = (long)n_in * max_out;
+    Grid go;
+    for (int d = 0; d < 3; d++) go.size[d] = out_size[d];
+    go.cap = next_pow2(2L * n_entries);
+    D3D_ALLOC(keys, uint64_t, A, go.cap);
+    D3D_ALLOC(vals, int32_t, A, go.cap);
+    D3D_ALLOC(loc_out, int32_t, A, (size_t)n_entries * 4 + 4);
+    D3D_ALLOC(nbr_dec, int32_t, A, (size_t)n_in * K + 1);
+    go.keys = keys;
+    go.vals = vals;
+    go.loc = loc_out;
+    D3D_HIP_CHECK(hipMemsetAsync(keys, 0xFF, sizeof(uint64_t) * go.cap, s));
+    D3D_HIP_CHECK(hipMemsetAsync(vals, 0xFF, sizeof(int32_t) * go.cap, s));
+    D3D_HIP_CHECK(hipMemsetAsync(nbr_dec, 0xFF, sizeof(int32_t) * ((size_t)n_in * K + 1), s));
+    Plan p;
+    int n_out = 0;
+    if (n_entries > 0) {
+      // raw forward table staged at the far end of the arena (size known only after the scan:
+      // bound it by n_entries rows)
+      size_t raw_bytes = ((size_t)n_entries * K + 1) * sizeof(int32_t);
+      if (A.used + raw_bytes + 12 * (size_t)n_entries * sizeof(int32_t) + (size_t)go.cap * 4 + (1 << 20) > A.cap) {
+        set_error("metadata arena exhausted while building a strided rulebook");
+        return D3D_ERR_NOMEM;
+      }
+      int32_t *nbr_fwd = (int32_t *)(A.base + ((A.cap - raw_bytes) & ~size_t(255)));
+      CapGuard guard(A, (A.cap - raw_bytes) & ~size_t(255));
+      size_t mark = A.used;
+      D3D_ALLOC(first, int32_t, A, go.cap);
+      D3D_ALLOC(eslot, int32_t, A, n_entries);
+      D3D_ALLOC(flag, int32_t, A, n_entries);
+      D3D_ALLOC(rank, int32_t, A, n_entries);
+      D3D_ALLOC(total, int32_t, A, 1);
+      D3D_HIP_CHECK(hipMemsetAsync(first, 0x7F, sizeof(int32_t) * go.cap, s));
+      hipLaunchKernelGGL(k_conv_insert, grid1d(n_entries), dim3(256), 0, s, gi->loc, n_entries, geo, keys, first, go.cap, eslot);
+      hipLaunchKernelGGL(k_flag_first, grid1d(n_entries), dim3(256), 0, s, eslot, first, (int)n_entries, flag);
+      int rc = scan_exclusive_i32(flag, rank, (int)n_entries, total, A, s);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_conv_assign, grid1d(n_entries), dim3(256), 0, s, gi->loc, n_entries, geo, eslot, flag, rank, vals, loc_out);
+      D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[0], total, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      D3D_HIP_CHECK(hipStreamSynchronize(s));
+      n_out = (int)*(int32_t *)&m->host_words[0];
+      D3D_HIP_CHECK(hipMemsetAsync(nbr_fwd, 0xFF, sizeof(int32_t) * ((size_t)n_out * K + 1), s));
+      hipLaunchKernelGGL(k_conv_fill, grid1d(n_entries), dim3(256), 0, s, gi->loc, n_entries, geo, K, eslot, vals, nbr_fwd, nbr_dec);
+      D3D_LAUNCH_CHECK();
+      A.used = mark;
+      rc = finalize_plan(m, nbr_fwd, n_out, K, p, s);
+      if (rc) return rc;
+    } else {
+      int rc = finalize_plan(m, nullptr, 0, K, p, s);
+      if (rc) return rc;
+    }
+    go.n = n_out;
+    m->grids[Size3{out_size[0], out_size[1], out_size[2]}] = go;
+    StridedRaw raw;
+    raw.nbr_dec = nbr_dec;
+    raw.n_in = n_in;
+    raw.out_size = Size3{out_size[0], out_size[1], out_size[2]};
+    m->strided_raw[key] = raw;
+    it = m->plans.emplace(key, p).first;
+  }
+  if (n_out_host) *n_out_host = it->second.n_rows;
+  if (n_rules_host) *n_rules_host = it->second.n_rules;
+  return D3D_OK;
+}
+
+int d3d_export_rules(d3d_meta *m, int kind, const int *in_size, const int *filt, const int *stride,
+                     int32_t *triples, long capacity, long *n_host, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(m && in_size && filt && n_host && (kind == 0 || kind == 1 || kind == 2), "bad arguments");
+  const Plan *p = find_plan(m, kind, in_size, filt, kind == 0 ? nullptr : stride);
+  if (!p) {
+    set_error("export: rulebook not built");
+    return D3D_ERR_STATE;
+  }
+  *n_host = 0;
+  if (p->n_rows == 0) return D3D_OK;
+  Arena &A = m->arena;
+  size_t mark = A.used;
+  D3D_ALLOC(cnt, unsigned long long, A, 1);
+  D3D_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), s));
+  const int npos = p->n_blk * 32;
+  // kind 2 (deconvolution plan): rows are fine sites = the rule's "in" side of the strided conv
+  hipLaunchKernelGGL(k_export_plan, grid1d((long)npos * p->K), dim3(256), 0, s, p->nbrT, p->rows, npos, p->K, kind == 2 ? 1 : 0, triples, capacity, cnt);
+  D3D_LAUNCH_CHECK();
+  D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[0], cnt, sizeof(long), hipMemcpyDeviceToHost, s));
+  D3D_HIP_CHECK(hipStreamSynchronize(s));
+  *n_host = m->host_words[0];
+  A.used = mark;
+  return D3D_OK;
+}
+
+int d3d_sparse_to_dense_forward(d3d_meta *m, const int *size, const float *in, int planes, int batch,
+                                float *out, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(m && size && out && planes > 0 && batch > 0, "bad arguments");
+  Grid *g = find_grid(m, size);
+  if (!g) {
+    set_error("sparse_to_dense: no grid of spatial size [%d,%d,%d]", size[0], size[1], size[2]);
+    return D3D_ERR_STATE;
+  }
+  size_t vol = (size_t)size[0] * size[1] * size[2];
+  D3D_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(float) * vol * planes * batch, s));
+  if (g->n == 0) return D3D_OK;
+  D3D_REQUIRE(in, "null input");
+  hipLaunchKernelGGL(k_sparse_to_dense, grid1d((long)g->n * planes), dim3(256), 0, s, in, planes, g->loc, g->n, size[0], size[1], size[2], out);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+}  // extern "C"

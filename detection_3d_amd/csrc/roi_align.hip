@@ -1,0 +1,214 @@
+// a21. RoIAlignRotated3D forward (maskrcnn_benchmark/csrc/cuda/ROIAlignRotated3D_cuda.cu:15-177).
+//  * dense variant: same contract as _C.roi_align_rotated_3d_forward (input [B,C,H,W,Z]);
+//  * sparse variant: samples the SparseConvNetTensor through its hash grid, so the 1.07 GB dense
+//    map of sparse_3d_to_dense_2d (sparseconvnet/tools_3d_2d.py:7-48) is never materialised.
+// Both keep the reference's `zsize > zsize` bound quirk (:27): z above the map is clamped.
+#include "d3d_internal.h"
+
+namespace d3d {
+
+struct RoiGeom {
+  int b;
+  float cw, ch, cz, bh, bw, bz, sh, sw, sz, cosT, sinT;
+  int gh, gw, gz;
+};
+__device__ __forceinline__ RoiGeom roi_geom(const float *r, float spatial_scale, int PH, int PW, int PZ,
+                                            int sampling_ratio) {
+  RoiGeom g;
+  g.b = (int)r[0];
+  g.cw = r[1] * spatial_scale;
+  g.ch = r[2] * spatial_scale;
+  g.cz = r[3] * spatial_scale;
+  float rw = r[4] * spatial_scale, rh = r[5] * spatial_scale, rz = r[6] * spatial_scale;
+  const float theta = (float)((double)r[7] * 3.14159265358979323846 / 180.0);
+  rw = fmaxf(rw, 1.f);
+  rh = fmaxf(rh, 1.f);
+  rz = fmaxf(rz, 1.f);
+  g.bh = rh / (float)PH;
+  g.bw = rw / (float)PW;
+  g.bz = rz / (float)PZ;
+  g.gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / PH);
+  g.gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / PW);
+  g.gz = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rz / PZ);
+  g.sh = (float)(-rh / 2.0);
+  g.sw = (float)(-rw / 2.0);
+  g.sz = (float)(-rz / 2.0);
+  g.cosT = (float)cos((double)theta);
+  g.sinT = (float)sin((double)theta);
+  return g;
+}
+// sample position of (bin, sub-sample) in map coordinates (:150-163)
+__device__ __forceinline__ void sample_pos(const RoiGeom &g, int ph, int pw, int pz, int iy, int ix,
+                                           int iz, float &y, float &x, float &z) {
+  const float yy = g.sh + ph * g.bh + (float)(iy + .5f) * g.bh / (float)g.gh;
+  const float xx = g.sw + pw * g.bw + (float)(ix + .5f) * g.bw / (float)g.gw;
+  const float zz = g.sz + pz * g.bz + (float)(iz + .5f) * g.bz / (float)g.gz;
+  x = xx * g.cosT + yy * g.sinT + g.cw;
+  y = yy * g.cosT - xx * g.sinT + g.ch;
+  z = zz + g.cz;
+}
+// interpolation set-up of bilinear_interpolate (:15-62): returns false for an empty sample
+struct Tri {
+  int yl, yh, xl, xh, zl, zh;
+  float ly, lx, lz, hy, hx, hz;
+};
+__device__ __forceinline__ bool tri_setup(float y, float x, float z, int H, int W, int Z, Tri &t) {
+  if (y < -1.0 || y > H || x < -1.0 || x > W || z < -1.0) return false;
+  if (y <= 0) y = 0;
+  if (x <= 0) x = 0;
+  if (z <= 0) z = 0;
+  t.yl = (int)y;
+  t.xl = (int)x;
+  t.zl = (int)z;
+  if (t.yl >= H - 1) { t.yh = t.yl = H - 1; y = (float)t.yl; } else t.yh = t.yl + 1;
+  if (t.xl >= W - 1) { t.xh = t.xl = W - 1; x = (float)t.xl; } else t.xh = t.xl + 1;
+  if (t.zl >= Z - 1) { t.zh = t.zl = Z - 1; z = (float)t.zl; } else t.zh = t.zl + 1;
+  t.ly = y - t.yl;
+  t.lx = x - t.xl;
+  t.lz = z - t.zl;
+  t.hy = 1. - t.ly;
+  t.hx = 1. - t.lx;
+  t.hz = 1. - t.lz;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k_roi_dense(const float *__restrict__ input, int C, int H,
+                                                   int W, int Z, const float *__restrict__ rois,
+                                                   long nthreads, float spatial_scale, int PH, int PW,
+                                                   int PZ, int sampling_ratio, float *__restrict__ out) {
+  long index = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (index >= nthreads) return;
+  const int pz = index % PZ;
+  const int pw = (index / PZ) % PW;
+  const int ph = (index / PZ / PW) % PH;
+  const int c = (index / PZ / PW / PH) % C;
+  const int n = index / PZ / PW / PH / C;
+  const RoiGeom g = roi_geom(rois + (size_t)n * 8, spatial_scale, PH, PW, PZ, sampling_ratio);
+  const float *d = input + ((size_t)g.b * C + c) * H * W * Z;
+  const float count = (float)(g.gh * g.gw * g.gz);
+  float acc = 0.f;
+  for (int iy = 0; iy < g.gh; iy++)
+    for (int ix = 0; ix < g.gw; ix++)
+      for (int iz = 0; iz < g.gz; iz++) {
+        float y, x, z;
+        sample_pos(g, ph, pw, pz, iy, ix, iz, y, x, z);
+        Tri t;
+        if (!tri_setup(y, x, z, H, W, Z, t)) continue;
+        const float v1 = d[(t.yl * W + t.xl) * Z + t.zl], v2 = d[(t.yl * W + t.xh) * Z + t.zl];
+        const float v3 = d[(t.yh * W + t.xl) * Z + t.zl], v4 = d[(t.yh * W + t.xh) * Z + t.zl];
+        const float v5 = d[(t.yl * W + t.xl) * Z + t.zh], v6 = d[(t.yl * W + t.xh) * Z + t.zh];
+        const float v7 = d[(t.yh * W + t.xl) * Z + t.zh], v8 = d[(t.yh * W + t.xh) * Z + t.zh];
+        const float w1 = t.hy * t.hx * t.hz, w2 = t.hy * t.lx * t.hz, w3 = t.ly * t.hx * t.hz, w4 = t.ly * t.lx * t.hz;
+        const float w5 = t.hy * t.hx * t.lz, w6 = t.hy * t.lx * t.lz, w7 = t.ly * t.hx * t.lz, w8 = t.ly * t.lx * t.lz;
+        acc += (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4 + w5 * v5 + w6 * v6 + w7 * v7 + w8 * v8);
+      }
+  out[index] = acc / count;
+}
+
+// Sparse variant.  Block = one RoI x one chunk of 64 channels; a wave walks bins; inside a bin the
+// 64 lanes first resolve (sub-sample, corner) -> (row, weight) in parallel through the hash grid
+// (8 sub-samples x 8 corners per step), then every lane accumulates its channel over the
+// broadcast list, reading feature rows coalesced.  The [64 x bins] tile is transposed through LDS
+// so that the [K, C, ph, pw, pz] output is written in contiguous runs.
+static constexpr int kRoiCch = 64;
+__global__ __launch_bounds__(256) void k_roi_sparse(
+    const uint64_t *__restrict__ keys, const int32_t *__restrict__ vals, int cap,
+    const float *__restrict__ feats, int C, int H, int W, int Z, const float *__restrict__ rois,
+    float spatial_scale, int PH, int PW, int PZ, int sampling_ratio, float *__restrict__ out) {
+  extern __shared__ float tile[];  // [kRoiCch][NB + 1]
+  const int n = blockIdx.x, cc = blockIdx.y;
+  const int NB = PH * PW * PZ, LD = NB + 1;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const RoiGeom g = roi_geom(rois + (size_t)n * 8, spatial_scale, PH, PW, PZ, sampling_ratio);
+  const int NS = g.gh * g.gw * g.gz;
+  const float count = (float)NS;
+  const int c = cc * kRoiCch + lane;
+  const bool cok = c < C;
+  for (int bin = wave; bin < NB; bin += 4) {
+    const int pz = bin % PZ, pw = (bin / PZ) % PW, ph = bin / (PZ * PW);
+    float acc = 0.f;
+    for (int s0 = 0; s0 < NS; s0 += 8) {
+      // ---- lanes = (sub-sample s0 + lane/8, corner lane%8) ----
+      const int s = s0 + (lane >> 3), corner = lane & 7;
+      int row = -1;
+      float wgt = 0.f;
+      if (s < NS) {
+        const int iz = s % g.gz, ix = (s / g.gz) % g.gw, iy = s / (g.gz * g.gw);
+        float y, x, z;
+        sample_pos(g, ph, pw, pz, iy, ix, iz, y, x, z);
+        Tri t;
+        if (tri_setup(y, x, z, H, W, Z, t)) {
+          const int zb = corner >> 2, yb = (corner >> 1) & 1, xb = corner & 1;
+          wgt = (yb ? t.ly : t.hy) * (xb ? t.lx : t.hx) * (zb ? t.lz : t.hz);
+          // dense index [y][x][z]: y runs over the tensor's 1st spatial axis, x over the 2nd
+          row = hash_find(keys, vals, cap, pack_key(g.b, yb ? t.yh : t.yl, xb ? t.xh : t.xl, zb ? t.zh : t.zl));
+        }
+      }
+      // ---- lanes = channels ----
+      const unsigned long long present = __ballot(row >= 0);
+#pragma unroll 1
+      for (int ss = 0; ss < 8; ss++) {
+        unsigned long long m = (present >> (ss * 8)) & 0xffull;
+        if (!m) continue;
+        float val = 0.f;
+        while (m) {
+          const int cr = __builtin_ctzll(m);
+          m &= m - 1;
+          const int src = ss * 8 + cr;
+          const int rr = __shfl(row, src, 64);
+          const float ww = __shfl(wgt, src, 64);
+          if (cok) val += ww * feats[(size_t)rr * C + c];
+        }
+        acc += val;
+      }
+    }
+    tile[lane * LD + bin] = acc / count;
+  }
+  __syncthreads();
+  const int nch = min(kRoiCch, C - cc * kRoiCch);
+  float *o = out + ((size_t)n * C + (size_t)cc * kRoiCch) * NB;
+  for (int idx = threadIdx.x; idx < nch * NB; idx += 256) o[idx] = tile[(idx / NB) * LD + idx % NB];
+}
+
+}  // namespace d3d
+
+using namespace d3d;
+
+extern "C" {
+
+int d3d_roi_align_rotated_3d_forward(const float *input, int B, int C, int H, int W, int Z,
+                                     const float *rois, int K, float spatial_scale, int ph, int pw,
+                                     int pz, int sampling_ratio, float *out, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Z > 0 && K >= 0 && ph > 0 && pw > 0 && pz > 0, "roi_align: bad shape");
+  if (K == 0) return D3D_OK;
+  D3D_REQUIRE(input && rois && out, "roi_align: null pointer");
+  long nthreads = (long)K * C * ph * pw * pz;
+  hipLaunchKernelGGL(k_roi_dense, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, input, C, H, W, Z, rois, nthreads, spatial_scale, ph, pw, pz, sampling_ratio, out);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+int d3d_roi_align_rotated_3d_sparse_forward(d3d_meta *m, const int *size, const float *feats, int C,
+                                            const int *crop, const float *rois, int K,
+                                            float spatial_scale, int ph, int pw, int pz,
+                                            int sampling_ratio, float *out, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(m && size && crop && C > 0 && K >= 0 && ph > 0 && pw > 0 && pz > 0, "roi_align_sparse: bad arguments");
+  auto it = m->grids.find(Size3{size[0], size[1], size[2]});
+  if (it == m->grids.end()) {
+    set_error("roi_align_sparse: no grid of spatial size [%d,%d,%d]", size[0], size[1], size[2]);
+    return D3D_ERR_STATE;
+  }
+  if (K == 0) return D3D_OK;
+  D3D_REQUIRE(feats && rois && out, "roi_align_sparse: null pointer");
+  const Grid &g = it->second;
+  const int NB = ph * pw * pz;
+  size_t lds = (size_t)kRoiCch * (NB + 1) * sizeof(float);
+  D3D_REQUIRE(lds <= 64 * 1024, "roi_align_sparse: pooled volume %d too large", NB);
+  hipLaunchKernelGGL(k_roi_sparse, dim3(K, (C + kRoiCch - 1) / kRoiCch), dim3(256), lds, s, g.keys, g.vals, g.cap, feats, C, crop[0], crop[1], crop[2], rois, spatial_scale, ph, pw, pz, sampling_ratio, out);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+}  // extern "C"

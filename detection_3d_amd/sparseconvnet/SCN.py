@@ -1,0 +1,253 @@
+"""Drop-in for the pybind module `sparseconvnet.SCN` of the reference
+(SparseConvNet/sparseconvnet/SCN/pybind.cpp:11-235, sparseconvnet.h:9-239), for the ops the
+3-D detection path uses.  Same names, argument order and ownership rules (outputs are passed in
+empty and resized by the callee), but every call lands in libd3d_hip.so on the current HIP stream
+-- including the rulebook construction, which the reference does on the CPU.
+
+Inference (forward) entry points only in this round; *_backward raise NotImplementedError.
+"""
+import ctypes
+import os
+
+import torch
+
+from .. import _lib
+from .._lib import check, ints, lib, ptr, require_gpu, stream_of
+
+_ARENA_BYTES = int(os.environ.get("D3D_ARENA_MB", "2048")) << 20
+_POOL = []          # recycled native metadata handles (one HBM arena each)
+_SCRATCH = {}       # per-device scratch tensors
+
+
+def _scratch(device, nbytes):
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 22), dtype=torch.uint8, device=device)
+        _SCRATCH[key] = buf
+    return buf
+
+
+def _size3(t):
+    v = [int(x) for x in (t.tolist() if hasattr(t, "tolist") else t)]
+    assert len(v) == 3, "only dimension 3 is built (Metadata_3)"
+    return v
+
+
+class Metadata_3(object):
+    """sparseconvnet.SCN.Metadata_3 (pybind.cpp:12-32).  Owns one HBM arena with the hash grids
+    and rulebooks of one batch."""
+
+    def __init__(self, arena_bytes=None):
+        self._dev = torch.cuda.current_device()
+        key_bytes = arena_bytes or _ARENA_BYTES
+        for i, (dev, nbytes, h) in enumerate(_POOL):
+            if dev == self._dev and nbytes == key_bytes:
+                _POOL.pop(i)
+                self._h, self._bytes = h, nbytes
+                check(lib().d3d_meta_clear(self._h))
+                return
+        h = ctypes.c_void_p()
+        check(lib().d3d_meta_create(ctypes.byref(h), key_bytes))
+        self._h, self._bytes = h, key_bytes
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and _lib._lib is not None:
+            if len(_POOL) < 4:
+                _POOL.append((self._dev, self._bytes, h))
+            else:
+                _lib._lib.d3d_meta_destroy(h)
+            self._h = None
+
+    def clear(self):
+        check(lib().d3d_meta_clear(self._h))
+
+    def getNActive(self, spatial_size):
+        n = ctypes.c_int(0)
+        check(lib().d3d_get_n_active(self._h, ints(_size3(spatial_size)), ctypes.byref(n)))
+        return n.value
+
+    def getSpatialLocations(self, spatial_size):
+        """int64 [nActive, 4] (x, y, z, batch) -- on the GPU (the reference returns a CPU tensor,
+        Metadata.cpp:148-168)."""
+        n = self.getNActive(spatial_size)
+        out = torch.empty((n, 4), dtype=torch.int64, device=torch.device("cuda", self._dev))
+        check(lib().d3d_get_spatial_locations(self._h, ints(_size3(spatial_size)), ptr(out), stream_of()))
+        return out
+
+    def arena_used(self):
+        n = ctypes.c_size_t(0)
+        check(lib().d3d_meta_arena_used(self._h, ctypes.byref(n)))
+        return n.value
+
+    # ---- debug exporters (canonical comparison with the oracle) ----
+    def export_input_rules(self, n_points):
+        n = self._in_active
+        dev = torch.device("cuda", self._dev)
+        off = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        idx = torch.empty(max(n_points, 1), dtype=torch.int32, device=dev)
+        check(lib().d3d_input_layer_export(self._h, ptr(off), ptr(idx), stream_of()))
+        return off, idx[:n_points]
+
+    def export_rules(self, kind, in_size, filter_size, stride=None, capacity=None):
+        """(in, out, offset) int32 triples of a built rulebook.  kind 0 submanifold, 1 strided,
+        2 deconvolution view of the strided rulebook."""
+        dev = torch.device("cuda", self._dev)
+        if capacity is None:
+            capacity = self.getNActive(in_size) * 32 + 32
+        trip = torch.empty((capacity, 3), dtype=torch.int32, device=dev)
+        n = ctypes.c_long(0)
+        st = ints(_size3(stride)) if stride is not None else ints([0, 0, 0])
+        check(lib().d3d_export_rules(self._h, kind, ints(_size3(in_size)), ints(_size3(filter_size)), st,
+                                     ptr(trip), capacity, ctypes.byref(n), stream_of()))
+        return trip[:n.value]
+
+
+def n_rulebook_bits():
+    return 32
+
+
+def pack_weight(weight):
+    """[fv, 1, Cin, Cout] reference layout -> MFMA k-interleaved layout (device tensor)."""
+    require_gpu(weight)
+    fv, groups, cin, cout = weight.shape
+    if groups != 1:
+        raise _lib.D3DError("groups != 1 is not supported")
+    n = lib().d3d_packed_weight_floats(fv, cin, cout)
+    if n == 0:
+        raise _lib.D3DError(f"unsupported conv shape fv={fv} Cin={cin} Cout={cout}")
+    packed = torch.empty(n, dtype=torch.float32, device=weight.device)
+    check(lib().d3d_pack_conv_weight(ptr(weight.detach()), fv, cin, cout, ptr(packed), stream_of()))
+    return packed
+
+
+def _coords_to_device(coords, device):
+    coords = coords.to(device=device, dtype=torch.int64, non_blocking=True)
+    return coords.contiguous()
+
+
+def InputLayer_updateOutput(m, spatial_size, input_coords, input_features, output_features,
+                            batch_size, mode):
+    """sparseconvnet.h:159-163.  input_coords int64 [N,3|4] on CPU or GPU."""
+    require_gpu(input_features)
+    dev = input_features.device
+    coords = _coords_to_device(input_coords, dev)
+    n, ncols = coords.shape
+    na = ctypes.c_int(0)
+    check(lib().d3d_input_layer_build(m._h, ptr(coords), n, ncols, ints(_size3(spatial_size)),
+                                      int(batch_size), int(mode), stream_of(), ctypes.byref(na)))
+    m._in_active = na.value
+    planes = input_features.shape[1]
+    output_features.resize_(na.value, planes)
+    feats = input_features.contiguous()
+    check(lib().d3d_input_layer_forward(m._h, ptr(feats), planes, ptr(output_features), stream_of()))
+
+
+def _conv_common(weight, packed):
+    fv, groups, cin, cout = weight.shape
+    if packed is None:
+        packed = pack_weight(weight)
+    return fv, cin, cout, packed
+
+
+def SubmanifoldConvolution_updateOutput(spatial_size, filter_size, m, input_features,
+                                        output_features, weight, bias, packed=None, residual=None):
+    """sparseconvnet.h:99-105; returns the multiply-add count like the reference."""
+    require_gpu(input_features, weight)
+    if bias is not None and bias.numel():
+        raise _lib.D3DError("bias is not supported (fpn_net.py builds every conv with bias=False)")
+    fv, cin, cout, packed = _conv_common(weight, packed)
+    size, filt = _size3(spatial_size), _size3(filter_size)
+    n = m.getNActive(size)
+    output_features.resize_(n, cout)
+    macs = ctypes.c_double(0)
+    check(lib().d3d_subm_conv_forward(m._h, ints(size), ints(filt), ptr(input_features), cin, ptr(packed),
+                                      cout, ptr(residual), ptr(output_features), stream_of(),
+                                      ctypes.byref(macs)))
+    return macs.value
+
+
+def Convolution_updateOutput(input_size, output_size, filter_size, filter_stride, m, input_features,
+                             output_features, weight, bias, packed=None):
+    """sparseconvnet.h:85-91."""
+    require_gpu(input_features, weight)
+    if bias is not None and bias.numel():
+        raise _lib.D3DError("bias is not supported")
+    fv, cin, cout, packed = _conv_common(weight, packed)
+    isz, osz, filt, st = _size3(input_size), _size3(output_size), _size3(filter_size), _size3(filter_stride)
+    n_out = ctypes.c_int(0)
+    check(lib().d3d_conv_prepare(m._h, ints(isz), ints(osz), ints(filt), ints(st), stream_of(),
+                                 ctypes.byref(n_out), None))
+    output_features.resize_(n_out.value, cout)
+    macs = ctypes.c_double(0)
+    check(lib().d3d_conv_forward(m._h, ints(isz), ints(osz), ints(filt), ints(st), ptr(input_features), cin,
+                                 ptr(packed), cout, ptr(output_features), stream_of(), ctypes.byref(macs)))
+    return macs.value
+
+
+def Deconvolution_updateOutput(input_size, output_size, filter_size, filter_stride, m, input_features,
+                               output_features, weight, bias, packed=None, residual=None):
+    """sparseconvnet.h:147-152: input = coarse, output = fine (rulebook of the matching Convolution)."""
+    require_gpu(input_features, weight)
+    if bias is not None and bias.numel():
+        raise _lib.D3DError("bias is not supported")
+    fv, cin, cout, packed = _conv_common(weight, packed)
+    isz, osz, filt, st = _size3(input_size), _size3(output_size), _size3(filter_size), _size3(filter_stride)
+    n = m.getNActive(osz)
+    output_features.resize_(n, cout)
+    macs = ctypes.c_double(0)
+    check(lib().d3d_deconv_forward(m._h, ints(isz), ints(osz), ints(filt), ints(st), ptr(input_features),
+                                   cin, ptr(packed), cout, ptr(residual), ptr(output_features), stream_of(),
+                                   ctypes.byref(macs)))
+    return macs.value
+
+
+def BatchNormalization_updateOutput(input_features, output_features, saveMean, saveInvStd, runningMean,
+                                    runningVar, weight, bias, eps, momentum, train, leakiness):
+    """sparseconvnet.h:21-26."""
+    require_gpu(input_features, saveMean, saveInvStd, runningMean, runningVar)
+    rows, planes = input_features.shape
+    output_features.resize_(rows, planes)
+    w = weight if (weight is not None and weight.numel()) else None
+    b = bias if (bias is not None and bias.numel()) else None
+    nbytes = lib().d3d_bn_scratch_bytes(planes)
+    scratch = _scratch(input_features.device, nbytes)
+    check(lib().d3d_bn_forward(ptr(input_features), ptr(output_features), rows, planes, ptr(saveMean),
+                               ptr(saveInvStd), ptr(runningMean), ptr(runningVar), ptr(w), ptr(b),
+                               float(eps), float(momentum), int(bool(train)), float(leakiness),
+                               ptr(scratch), scratch.numel(), stream_of()))
+
+
+def batch_stats(features):
+    """features.mean(0), features.var(0) (unbiased) as batchNormalization.py:54-55 computes them."""
+    require_gpu(features)
+    rows, planes = features.shape
+    mean = torch.empty(planes, dtype=torch.float32, device=features.device)
+    var = torch.empty_like(mean)
+    nbytes = lib().d3d_bn_scratch_bytes(planes)
+    scratch = _scratch(features.device, nbytes)
+    check(lib().d3d_bn_batch_stats(ptr(features), rows, planes, ptr(mean), ptr(var), ptr(scratch),
+                                   scratch.numel(), stream_of()))
+    return mean, var
+
+
+def SparseToDense_updateOutput(spatial_size, m, input_features, output, nPlanes, batch_size=1):
+    """sparseconvnet.h:214-217: dense [B, C, X, Y, Z], zero filled."""
+    require_gpu(input_features)
+    size = _size3(spatial_size)
+    output.resize_(batch_size, nPlanes, size[0], size[1], size[2])
+    check(lib().d3d_sparse_to_dense_forward(m._h, ints(size), ptr(input_features), int(nPlanes),
+                                            int(batch_size), ptr(output), stream_of()))
+
+
+def _no_backward(*a, **k):
+    raise NotImplementedError("backward entry points are not built in this round (SURVEY.md 8(a) a7)")
+
+
+InputLayer_updateGradInput = _no_backward
+SubmanifoldConvolution_backward = _no_backward
+Convolution_backward = _no_backward
+Deconvolution_backward = _no_backward
+BatchNormalization_backward = _no_backward
+SparseToDense_updateGradInput = _no_backward

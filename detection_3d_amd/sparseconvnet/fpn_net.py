@@ -1,0 +1,140 @@
+"""Sparse 3-D FPN backbone: same module tree / parameter names as
+SparseConvNet/sparseconvnet/fpn_net.py:12-137 (so `backbone.*` checkpoint keys load unchanged),
+same outputs as its forward_fpn (:168-265), executed by the HIP ops of libd3d_hip.so.
+
+Two execution switches that do not change any returned tensor:
+  * fuse_adds     -- residual / lateral additions run in the epilogue of the producing
+                     convolution instead of a separate AddTable / add_feature_planes pass;
+  * skip_unused   -- the top-down levels whose outputs nothing consumes for the configured
+                     fpn_scales_from_top / roi_scales_from_top (m_ups[5..7] for fpn432) are not
+                     computed; the reference computes and discards them (fpn_net.py:186-196).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import modules as scn
+
+
+class FPN_Net(torch.nn.Module):
+    def __init__(self, full_scale, dimension, raw_elements, reps, nPlanesF, nPlaneM, residual_blocks,
+                 fpn_scales_from_top, roi_scales_from_top, downsample, rpn_map_sizes,
+                 rpn_3d_2d_selector, leakiness=0, voxel_scale=None, bn_momentum=0.9,
+                 track_running_stats=True, fuse_adds=True, skip_unused=True):
+        nn.Module.__init__(self)
+        self.bn_momentum = bn_momentum
+        self.track_running_stats = track_running_stats
+        self.dimension = dimension
+        self.down_kernels, self.down_strides = downsample[0], downsample[1]
+        self.fpn_scales_from_top = list(fpn_scales_from_top)
+        self.roi_scales_from_top = list(roi_scales_from_top)
+        self.residual_blocks = residual_blocks
+        self.reps = reps
+        self.fuse_adds, self.skip_unused = fuse_adds, skip_unused
+        n_scales = len(nPlanesF)
+        assert len(self.down_kernels) == n_scales - 1 == len(self.down_strides)
+        in_channels = sum({'xyz': 3, 'color': 3, 'normal': 3}[e] for e in raw_elements)
+        bn = dict(momentum=bn_momentum, track_running_stats=track_running_stats)
+
+        self.layers_in_0 = scn.Sequential(scn.InputLayer(dimension, full_scale, mode=4))
+        self.layers_in = scn.Sequential(
+            scn.InputLayer(dimension, full_scale, mode=4),
+            scn.SubmanifoldConvolution(dimension, in_channels, nPlanesF[0], 3, False))
+        self.layers_out = scn.Sequential(scn.BatchNormReLU(nPlanesF[0], **bn), scn.OutputLayer(dimension))
+        self.linear = nn.Linear(nPlanesF[0], 20)
+        self.voxel_scale = voxel_scale
+        self.rpn_map_sizes = np.array(rpn_map_sizes)
+        self.rpn_3d_2d_selector = list(rpn_3d_2d_selector)
+        self.convs_pro2d = nn.ModuleList(
+            [scn.Convolution(dimension, nPlaneM, nPlaneM, [1, 1, int(z)], [1, 1, 1], False)
+             for z in self.rpn_map_sizes[:, -1]])
+
+        def block(m, a, b):
+            if residual_blocks:
+                assert a == b, "NetworkInNetwork branch is never taken by the detector configs"
+                m.add(scn.ConcatTable()
+                      .add(scn.Identity())
+                      .add(scn.Sequential()
+                           .add(scn.BatchNormLeakyReLU(a, leakiness=leakiness, **bn))
+                           .add(scn.SubmanifoldConvolution(dimension, a, b, 3, False))
+                           .add(scn.BatchNormLeakyReLU(b, leakiness=leakiness, **bn))
+                           .add(scn.SubmanifoldConvolution(dimension, b, b, 3, False)))
+                      ).add(scn.AddTable())
+            else:
+                m.add(scn.Sequential()
+                      .add(scn.BatchNormLeakyReLU(a, leakiness=leakiness, **bn))
+                      .add(scn.SubmanifoldConvolution(dimension, a, b, 3, False)))
+
+        self.m_downs, self.m_shortcuts = nn.ModuleList(), nn.ModuleList()
+        for k in range(n_scales):
+            m = scn.Sequential()
+            if k > 0:
+                m.add(scn.Sequential()
+                      .add(scn.BatchNormLeakyReLU(nPlanesF[k - 1], leakiness=leakiness, **bn))
+                      .add(scn.Convolution(dimension, nPlanesF[k - 1], nPlanesF[k],
+                                           self.down_kernels[k - 1], self.down_strides[k - 1], False)))
+            for _ in range(reps):
+                block(m, nPlanesF[k], nPlanesF[k])
+            self.m_downs.append(m)
+            self.m_shortcuts.append(scn.SubmanifoldConvolution(dimension, nPlanesF[k], nPlaneM, 1, False))
+
+        self.m_ups, self.m_mergeds = nn.ModuleList(), nn.ModuleList()
+        for k in range(n_scales - 1, 0, -1):
+            self.m_ups.append(scn.Sequential()
+                              .add(scn.BatchNormLeakyReLU(nPlaneM, leakiness=leakiness, **bn))
+                              .add(scn.Deconvolution(dimension, nPlaneM, nPlaneM, self.down_kernels[k - 1],
+                                                     self.down_strides[k - 1], False)))
+            self.m_mergeds.append(scn.SubmanifoldConvolution(dimension, nPlaneM, nPlaneM, 3, False))
+
+    # ------------------------------------------------------------------------------------
+    def forward(self, net0):
+        net1 = self.layers_in(net0)
+        return self.forward_fpn(net1)
+
+    def _run_down(self, m, net):
+        if not (self.fuse_adds and self.residual_blocks):
+            return m(net)
+        children = list(m._modules.values())
+        i = 0
+        while i < len(children):
+            c = children[i]
+            if isinstance(c, scn.ConcatTable):   # [Identity, (BN, conv, BN, conv)] followed by AddTable
+                seq = c._modules['1']
+                y = seq[0](net)
+                y = seq[1](y)
+                y = seq[2](y)
+                net = seq[3](y, residual=net)     # out = conv(..) + identity branch
+                i += 2
+            else:
+                net = c(net)
+                i += 1
+        return net
+
+    def forward_fpn(self, net):
+        n_scales = len(self.m_downs)
+        downs = []
+        for m in self.m_downs:
+            net = self._run_down(m, net)
+            downs.append(net)
+        net = self.m_shortcuts[-1](net)
+        ups = [net]
+        needed = max(self.fpn_scales_from_top + self.roi_scales_from_top) if self.skip_unused else n_scales - 1
+        for k in range(min(n_scales - 1, needed)):
+            j = n_scales - 2 - k
+            shortcut = self.m_shortcuts[j](downs[j])
+            if self.fuse_adds:
+                up = self.m_ups[k]
+                net = up[1](up[0](net), residual=shortcut)
+            else:
+                net = scn.add_feature_planes([self.m_ups[k](net), shortcut])
+            ups.append(self.m_mergeds[k](net))
+        rpn_maps_3d = [ups[i] for i in self.fpn_scales_from_top]
+        selected_2d = {i - len(rpn_maps_3d) for i in self.rpn_3d_2d_selector if i >= len(rpn_maps_3d)}
+        rpn_maps_2d = [self.convs_pro2d[i](rpn_maps_3d[i]) if (i in selected_2d or not self.skip_unused) else None
+                       for i in range(len(rpn_maps_3d))]
+        rpn_maps = rpn_maps_3d + rpn_maps_2d
+        rpn_maps = [rpn_maps[i] for i in self.rpn_3d_2d_selector]
+        roi_maps = [ups[i] for i in self.roi_scales_from_top]
+        for i in range(len(rpn_maps_3d)):
+            assert rpn_maps_3d[i].spatial_size.tolist() == [int(v) for v in self.rpn_map_sizes[i]]
+        return rpn_maps, roi_maps

@@ -1,0 +1,306 @@
+"""nn.Module layer of the sparse backbone, mirroring the class names, constructor arguments,
+parameter names/shapes and forward semantics of SparseConvNet/sparseconvnet/*.py so that
+reference checkpoints load unchanged (checkpoint surface).
+
+Forward only (inference) in this round: all ops run under torch.no_grad().
+"""
+import torch
+from torch.nn import Module, Parameter
+
+from . import SCN
+
+
+def toLongTensor(dimension, x):
+    """sparseconvnet/utils.py:11-18."""
+    if isinstance(x, torch.Tensor):
+        return x.to(torch.int64)
+    if isinstance(x, (list, tuple)):
+        assert len(x) == dimension
+        return torch.tensor([int(v) for v in x], dtype=torch.int64)
+    return torch.full((dimension,), int(x), dtype=torch.int64)
+
+
+def Metadata(dim):
+    """sparseconvnet/metadata.py:15-16."""
+    assert dim == 3, "only Metadata_3 is built"
+    return SCN.Metadata_3()
+
+
+class SparseConvNetTensor(object):
+    """sparseconvnet/sparseConvNetTensor.py:12-55."""
+
+    def __init__(self, features=None, metadata=None, spatial_size=None):
+        self.features = features
+        self.metadata = metadata
+        self.spatial_size = spatial_size
+
+    def get_spatial_locations(self, spatial_size=None):
+        if spatial_size is None:
+            spatial_size = self.spatial_size
+        return self.metadata.getSpatialLocations(spatial_size)
+
+    def to(self, device):
+        self.features = self.features.to(device)
+        return self
+
+    def cuda(self):
+        self.features = self.features.cuda()
+        return self
+
+    def __repr__(self):
+        return (f"SparseConvNetTensor<<features.shape={tuple(self.features.shape)},"
+                f"spatial size={self.spatial_size.tolist()}>>")
+
+
+def _like(inp, features, spatial_size=None):
+    return SparseConvNetTensor(features, inp.metadata, inp.spatial_size if spatial_size is None else spatial_size)
+
+
+class _PackedWeightMixin(object):
+    """Caches the MFMA-layout copy of `weight` until the parameter changes."""
+
+    def _packed(self):
+        w = self.weight
+        tag = (w._version, w.data_ptr(), w.device)
+        if getattr(self, "_packed_tag", None) != tag:
+            self._packed_w = SCN.pack_weight(w)
+            self._packed_tag = tag
+        return self._packed_w
+
+
+class InputLayer(Module):
+    """sparseconvnet/ioLayers.py:15-65.  input = [coords int64 [N,3|4], features [N,C](, batch_size)]."""
+
+    def __init__(self, dimension, spatial_size, mode=3):
+        Module.__init__(self)
+        self.dimension = dimension
+        self.spatial_size = toLongTensor(dimension, spatial_size)
+        self.mode = mode
+        self.device = None
+
+    def to(self, device):
+        self.device = device
+        return self
+
+    @torch.no_grad()
+    def forward(self, input):
+        out = SparseConvNetTensor(metadata=Metadata(self.dimension), spatial_size=self.spatial_size)
+        feats = input[1].to(self.device) if self.device else input[1]
+        out.features = feats.new_empty(0)
+        SCN.InputLayer_updateOutput(out.metadata, self.spatial_size, input[0], feats, out.features,
+                                    0 if len(input) == 2 else input[2], self.mode)
+        return out
+
+
+class SubmanifoldConvolution(Module, _PackedWeightMixin):
+    """sparseconvnet/submanifoldConvolution.py:14-59; weight [fv, groups, nIn/groups, nOut/groups]."""
+
+    def __init__(self, dimension, nIn, nOut, filter_size, bias, groups=1):
+        Module.__init__(self)
+        assert groups == 1 and not bias, "groups/bias are not used by FPN_Net and not built"
+        self.dimension, self.groups, self.nIn, self.nOut = dimension, groups, nIn, nOut
+        self.filter_size = toLongTensor(dimension, filter_size)
+        self.filter_volume = int(self.filter_size.prod().item())
+        std = (2.0 * groups / nIn / self.filter_volume) ** 0.5
+        self.weight = Parameter(torch.empty(self.filter_volume, groups, nIn // groups, nOut // groups).normal_(0, std))
+
+    @torch.no_grad()
+    def forward(self, input, residual=None):
+        assert input.features.nelement() == 0 or input.features.size(1) == self.nIn, (self.nIn, self.nOut)
+        out = _like(input, input.features.new_empty(0))
+        SCN.SubmanifoldConvolution_updateOutput(input.spatial_size, self.filter_size, input.metadata,
+                                                input.features, out.features, self.weight, None,
+                                                packed=self._packed(),
+                                                residual=None if residual is None else residual.features)
+        return out
+
+    def input_spatial_size(self, out_size):
+        return out_size
+
+
+class Convolution(Module, _PackedWeightMixin):
+    """sparseconvnet/convolution.py:13-70."""
+
+    def __init__(self, dimension, nIn, nOut, filter_size, filter_stride, bias, groups=1):
+        Module.__init__(self)
+        assert groups == 1 and not bias
+        self.dimension, self.groups, self.nIn, self.nOut = dimension, groups, nIn, nOut
+        self.filter_size = toLongTensor(dimension, filter_size)
+        self.filter_volume = int(self.filter_size.prod().item())
+        self.filter_stride = toLongTensor(dimension, filter_stride)
+        std = (2.0 * groups / nIn / self.filter_volume) ** 0.5
+        self.weight = Parameter(torch.empty(self.filter_volume, groups, nIn // groups, nOut // groups).normal_(0, std))
+
+    @torch.no_grad()
+    def forward(self, input):
+        assert input.features.nelement() == 0 or input.features.size(1) == self.nIn
+        out_size = (input.spatial_size - self.filter_size) // self.filter_stride + 1
+        assert ((out_size - 1) * self.filter_stride + self.filter_size == input.spatial_size).all(), \
+            (input.spatial_size, out_size, self.filter_size, self.filter_stride)
+        out = _like(input, input.features.new_empty(0), out_size)
+        SCN.Convolution_updateOutput(input.spatial_size, out_size, self.filter_size, self.filter_stride,
+                                     input.metadata, input.features, out.features, self.weight, None,
+                                     packed=self._packed())
+        return out
+
+    def input_spatial_size(self, out_size):
+        return (out_size - 1) * self.filter_stride + self.filter_size
+
+
+class Deconvolution(Module, _PackedWeightMixin):
+    """sparseconvnet/deconvolution.py:13-47."""
+
+    def __init__(self, dimension, nIn, nOut, filter_size, filter_stride, bias, groups=1):
+        Module.__init__(self)
+        assert groups == 1 and not bias
+        self.dimension, self.groups, self.nIn, self.nOut = dimension, groups, nIn, nOut
+        self.filter_size = toLongTensor(dimension, filter_size)
+        self.filter_volume = int(self.filter_size.prod().item())
+        self.filter_stride = toLongTensor(dimension, filter_stride)
+        std = (2.0 * groups / nIn / self.filter_volume) ** 0.5
+        self.weight = Parameter(torch.empty(self.filter_volume, groups, nIn // groups, nOut // groups).normal_(0, std))
+
+    @torch.no_grad()
+    def forward(self, input, residual=None):
+        assert input.features.nelement() == 0 or input.features.size(1) == self.nIn
+        out_size = (input.spatial_size - 1) * self.filter_stride + self.filter_size
+        out = _like(input, input.features.new_empty(0), out_size)
+        SCN.Deconvolution_updateOutput(input.spatial_size, out_size, self.filter_size, self.filter_stride,
+                                       input.metadata, input.features, out.features, self.weight, None,
+                                       packed=self._packed(),
+                                       residual=None if residual is None else residual.features)
+        return out
+
+    def input_spatial_size(self, out_size):
+        return (out_size - self.filter_size) // self.filter_stride + 1
+
+
+class BatchNormalization(Module):
+    """sparseconvnet/batchNormalization.py:13-68.  `momentum` is the RETENTION factor of the
+    running statistics (SCN/CPU/BatchNormalization.cpp:32-36)."""
+
+    def __init__(self, nPlanes, eps=1e-4, momentum=0.9, affine=True, leakiness=1, track_running_stats=True):
+        Module.__init__(self)
+        self.nPlanes, self.eps, self.momentum, self.affine, self.leakiness = nPlanes, eps, momentum, affine, leakiness
+        self.register_buffer("running_mean", torch.zeros(nPlanes))
+        self.register_buffer("running_var", torch.ones(nPlanes))
+        if affine:
+            self.weight = Parameter(torch.ones(nPlanes))
+            self.bias = Parameter(torch.zeros(nPlanes))
+        self.track_running_stats = track_running_stats
+
+    @torch.no_grad()
+    def forward(self, input):
+        f = input.features
+        assert f.nelement() == 0 or f.size(1) == self.nPlanes, (self.nPlanes, f.shape)
+        if self.training or self.track_running_stats:
+            mean, var = self.running_mean, self.running_var
+        else:  # batchNormalization.py:53-55: batch statistics stand in for the running ones
+            mean, var = SCN.batch_stats(f)
+        out = _like(input, f.new_empty(0))
+        save_mean = f.new_empty(self.nPlanes)
+        save_invstd = f.new_empty(self.nPlanes)
+        SCN.BatchNormalization_updateOutput(f, out.features, save_mean, save_invstd, mean, var,
+                                            self.weight if self.affine else None,
+                                            self.bias if self.affine else None, self.eps, self.momentum,
+                                            self.training, self.leakiness)
+        return out
+
+    def input_spatial_size(self, out_size):
+        return out_size
+
+
+class BatchNormReLU(BatchNormalization):
+    def __init__(self, nPlanes, eps=1e-4, momentum=0.9, track_running_stats=True):
+        BatchNormalization.__init__(self, nPlanes, eps, momentum, True, 0, track_running_stats)
+
+
+class BatchNormLeakyReLU(BatchNormalization):
+    def __init__(self, nPlanes, eps=1e-4, momentum=0.9, leakiness=0.333, track_running_stats=True):
+        BatchNormalization.__init__(self, nPlanes, eps, momentum, True, leakiness, track_running_stats)
+
+
+class Sequential(torch.nn.Sequential):
+    """sparseconvnet/sequential.py:9-27."""
+
+    def add(self, module):
+        self._modules[str(len(self._modules))] = module
+        return self
+
+    def input_spatial_size(self, out_size):
+        for m in reversed(self._modules):
+            out_size = self._modules[m].input_spatial_size(out_size)
+        return out_size
+
+
+class Identity(Module):
+    def forward(self, input):
+        return input
+
+    def input_spatial_size(self, out_size):
+        return out_size
+
+
+class ConcatTable(torch.nn.Sequential):
+    """sparseconvnet/tables.py:44-55: applies every child to the same input."""
+
+    def forward(self, input):
+        return [module(input) for module in self._modules.values()]
+
+    def add(self, module):
+        self._modules[str(len(self._modules))] = module
+        return self
+
+    def input_spatial_size(self, out_size):
+        return self._modules["0"].input_spatial_size(out_size)
+
+
+def add_feature_planes(inputs):
+    """sparseconvnet/utils.py:61-66 (two operands on this path)."""
+    from .._lib import check, lib, ptr, stream_of
+    assert len(inputs) >= 2
+    acc = inputs[0].features
+    for other in inputs[1:]:
+        out = torch.empty_like(acc)
+        check(lib().d3d_add(ptr(acc), ptr(other.features.contiguous()), ptr(out), acc.numel(), stream_of()))
+        acc = out
+    return _like(inputs[0], acc)
+
+
+class AddTable(torch.nn.Sequential):
+    """sparseconvnet/tables.py:28-41."""
+
+    def forward(self, input):
+        return add_feature_planes(input)
+
+    def input_spatial_size(self, out_size):
+        return out_size
+
+
+class OutputLayer(Module):
+    """sparseconvnet/ioLayers.py (OutputLayer): only constructed, never called, by FPN_Net."""
+
+    def __init__(self, dimension):
+        Module.__init__(self)
+        self.dimension = dimension
+
+    def forward(self, input):
+        raise NotImplementedError("OutputLayer is unused on the detection path (fpn_net.py:47-49)")
+
+
+class SparseToDense(Module):
+    """sparseconvnet/sparseToDense.py: dense [B, C, X, Y, Z]."""
+
+    def __init__(self, dimension, nPlanes):
+        Module.__init__(self)
+        self.dimension, self.nPlanes = dimension, nPlanes
+
+    @torch.no_grad()
+    def forward(self, input, batch_size=None):
+        if batch_size is None:
+            loc = input.get_spatial_locations()
+            batch_size = int(loc[:, 3].max().item()) + 1 if loc.shape[0] else 1
+        out = input.features.new_empty(0)
+        SCN.SparseToDense_updateOutput(input.spatial_size, input.metadata, input.features, out,
+                                       self.nPlanes, batch_size)
+        return out

@@ -1,0 +1,51 @@
+"""Synthetic SYNBIM-shaped scenes and box sets.
+
+The dataset itself is not available (reference README.md:11), so bench.py and the parity
+tests use this generator: points on wall / floor / ceiling planes of a 25 x 19 x 2.7 m
+building, 9 feature channels (xyz, colour, normal) as in
+data3d/suncg_utils/suncg_dataset.py:146-149.
+"""
+import numpy as np
+
+
+def make_scene(seed=0, n_points=500_000, extent=(25.0, 19.0, 2.7)):
+    """Returns pcl float32 [N, 9] (xyz, rgb, normal) in metres."""
+    rng = np.random.RandomState(seed)
+    ex, ey, ez = extent
+    n = n_points
+    kind = rng.choice(4, size=n, p=[0.3, 0.3, 0.2, 0.2])
+    xyz = rng.rand(n, 3) * np.array([ex, ey, ez])
+    nrm = np.zeros((n, 3), np.float64)
+    xs = np.linspace(0.05, ex - 0.05, 6)
+    ys = np.linspace(0.05, ey - 0.05, 4)
+    m = kind == 0
+    xyz[m, 0] = xs[rng.randint(0, len(xs), m.sum())]
+    nrm[m, 0] = 1
+    m = kind == 1
+    xyz[m, 1] = ys[rng.randint(0, len(ys), m.sum())]
+    nrm[m, 1] = 1
+    m = kind == 2
+    xyz[m, 2] = 0.02
+    nrm[m, 2] = 1
+    m = kind == 3
+    xyz[m, 2] = ez - 0.02
+    nrm[m, 2] = -1
+    rgb = rng.rand(n, 3)
+    return np.concatenate([xyz, rgb, nrm], 1).astype(np.float32)
+
+
+def make_boxes(seed=0, n=2000, extent=(25.0, 19.0, 2.7)):
+    """Wall-like boxes in yx_zb mode [xc, yc, z_bot, dy(thickness), dx(length), dz, yaw] + scores."""
+    rng = np.random.RandomState(seed)
+    ex, ey, ez = extent
+    b = np.zeros((n, 7), np.float64)
+    b[:, 0] = rng.rand(n) * ex
+    b[:, 1] = rng.rand(n) * ey
+    b[:, 2] = rng.rand(n) * 0.3
+    b[:, 3] = 0.08 + rng.rand(n) * 0.22
+    b[:, 4] = 0.5 + rng.rand(n) * 5.5
+    b[:, 5] = 1.0 + rng.rand(n) * 1.8
+    base = np.array([0, np.pi / 2, -np.pi / 2, np.pi / 4, -np.pi / 4])
+    b[:, 6] = base[rng.randint(0, 5, n)] + rng.randn(n) * 0.02
+    scores = rng.rand(n)
+    return b.astype(np.float32), scores.astype(np.float32)

@@ -1,0 +1,170 @@
+/*
+ * d3d_hip.h -- C ABI of libd3d_hip.so, the MI355X (gfx950) implementation of the hot path of
+ * zhupan007/Detection_3D:  points -> voxel hash-scatter -> sparse-3D-conv rulebooks +
+ * gather-GEMM-scatter -> rotated IoU / NMS -> rotated 3-D RoIAlign.
+ *
+ * Conventions
+ *  - every pointer argument is a DEVICE pointer unless its name ends in _host;
+ *  - every function takes the hipStream_t to enqueue on (passed as void* so that this header
+ *    needs no HIP include) and returns 0 on success or a negative d3d_status; it never throws.
+ *    d3d_last_error() returns a thread-local message for the last failure;
+ *  - functions that must tell the host a size (number of active sites ...) synchronise the
+ *    stream once; all others are asynchronous;
+ *  - feature matrices are row-major fp32 [rows, planes]; coordinates int64 [n, 3|4] (x,y,z[,b]).
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the reference
+ * repository root; SCN = SparseConvNet/sparseconvnet/SCN).
+ */
+#ifndef D3D_HIP_H
+#define D3D_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  D3D_OK = 0,
+  D3D_ERR_ARG = -1,      /* bad argument (shape, null pointer, unsupported mode) */
+  D3D_ERR_HIP = -2,      /* a HIP runtime call failed */
+  D3D_ERR_NOMEM = -3,    /* metadata arena exhausted */
+  D3D_ERR_STATE = -4,    /* grid / rulebook not built (call order) */
+  D3D_ERR_UNSUPPORTED = -5
+} d3d_status;
+
+const char *d3d_last_error(void);
+int d3d_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Metadata: replaces class sparseconvnet.SCN.Metadata_3 (SCN/pybind.cpp:12-32,
+ * SCN/Metadata/Metadata.h:36-130).  Owns the per-scale hash grids and the lazily built,
+ * cached rulebooks ("plans"), all resident in one HBM arena of `arena_bytes`.
+ * Not re-entrant per object (same as the reference: lazy cache mutation).                  */
+typedef struct d3d_meta d3d_meta;
+int d3d_meta_create(d3d_meta **out, size_t arena_bytes);
+int d3d_meta_destroy(d3d_meta *m);
+int d3d_meta_clear(d3d_meta *m);                       /* Metadata::clear, Metadata.cpp:30-45 */
+int d3d_meta_arena_used(d3d_meta *m, size_t *bytes_host);
+
+/* a1. data3d/suncg_utils/suncg_dataset.py:97-177: a = xyz*scale in fp64, shift by per-axis min,
+ * drop points outside [0, full_scale), trunc -> int64; feats[:,0:3] = a/scale.
+ * pcl fp32 [n, nfeat] (xyz first).  coords_out int64 [n,3], feats_out fp32 [n,nfeat]
+ * (compacted, input order preserved).  Synchronises; *n_kept_host = rows written.            */
+int d3d_voxelize(const float *pcl, int n, int nfeat, double scale, const int *full_scale_host,
+                 int64_t *coords_out, float *feats_out, int *n_kept_host, void *scratch,
+                 size_t scratch_bytes, void *stream);
+size_t d3d_voxelize_scratch_bytes(int n);
+
+/* a2/a3. InputLayer_updateOutput (SCN/sparseconvnet.h:159-163; SCN/Metadata/IOLayersRules.h:19-125;
+ * SCN/CPU/IOLayers.cpp:11-47), split into the hash build (sizes) and the feature pass.
+ * mode 3 = sum, 4 = mean.  Site ids follow first occurrence in input order (bit-exact with
+ * the reference); duplicates are accumulated in input order.                                */
+int d3d_input_layer_build(d3d_meta *m, const int64_t *coords, int n, int ncols,
+                          const int *spatial_size_host, int batch_size, int mode, void *stream,
+                          int *n_active_host);
+int d3d_input_layer_forward(d3d_meta *m, const float *feats, int planes, float *out, void *stream);
+/* debug exporter: rule table rows [count, idx0..] (IOLayersRules.h:112-124) as CSR.
+ * offsets int32 [n_active+1], idx int32 [n].                                                 */
+int d3d_input_layer_export(d3d_meta *m, int32_t *offsets, int32_t *idx, void *stream);
+
+/* Metadata::getNActive / getSpatialLocations (SCN/Metadata/Metadata.cpp:148-168): int64 [n,4]. */
+int d3d_get_n_active(d3d_meta *m, const int *spatial_size_host, int *n_host);
+int d3d_get_spatial_locations(d3d_meta *m, const int *spatial_size_host, int64_t *out, void *stream);
+
+/* a4. Metadata::getSubmanifoldRuleBook (Metadata.cpp:430-443; SubmanifoldConvolutionRules.h:27-45).
+ * Builds (or finds cached) the rulebook; *n_rules_host = number of (in,out) pairs.           */
+int d3d_subm_prepare(d3d_meta *m, const int *spatial_size_host, const int *filter_host,
+                     void *stream, long *n_rules_host);
+/* a5. Metadata::getRuleBook (Metadata.cpp:485-510; ConvolutionRules.h:12-34): builds the output
+ * grid of spatial size `out_size` and the rulebook.  Output sites are numbered by first touch
+ * while visiting input sites in id order (canonical; the reference's order is hash-iteration
+ * dependent).                                                                                */
+int d3d_conv_prepare(d3d_meta *m, const int *in_size_host, const int *out_size_host,
+                     const int *filter_host, const int *stride_host, void *stream,
+                     int *n_out_host, long *n_rules_host);
+/* debug exporter: rulebook as (in,out,offset) int32 triples in unspecified order; capacity in
+ * triples; *n_host receives the count.  kind: 0 submanifold (out_size ignored), 1 strided.    */
+int d3d_export_rules(d3d_meta *m, int kind, const int *in_size_host, const int *filter_host,
+                     const int *stride_host, int32_t *triples, long capacity, long *n_host,
+                     void *stream);
+
+/* Conv weights: reference layout [filter_volume, groups=1, Cin, Cout]
+ * (sparseconvnet/submanifoldConvolution.py:24-26).  The kernels read a k-interleaved copy
+ * [fv][ceil(Cin/8)*2][Cout][4]; pack once per weight update.                                 */
+size_t d3d_packed_weight_floats(int filter_volume, int cin, int cout);
+int d3d_pack_conv_weight(const float *w, int filter_volume, int cin, int cout, float *packed,
+                         void *stream);
+
+/* a6. SubmanifoldConvolution_updateOutput (SCN/sparseconvnet.h:99-105), Convolution_updateOutput
+ * (:85-91), Deconvolution_updateOutput (:147-152): out[r_out] = sum_k in[r_in(k)] @ W[k],
+ * bias-free (fpn_net.py builds every conv with bias=False).  `residual` (may be null) is added
+ * in the epilogue (fuses sparseconvnet/tables.py AddTable).  *macs_host (may be null)
+ * receives rules*Cin*Cout like the reference's return value.                                 */
+int d3d_subm_conv_forward(d3d_meta *m, const int *spatial_size_host, const int *filter_host,
+                          const float *in, int cin, const float *packed_w, int cout,
+                          const float *residual, float *out, void *stream, double *macs_host);
+int d3d_conv_forward(d3d_meta *m, const int *in_size_host, const int *out_size_host,
+                     const int *filter_host, const int *stride_host, const float *in, int cin,
+                     const float *packed_w, int cout, float *out, void *stream, double *macs_host);
+int d3d_deconv_forward(d3d_meta *m, const int *in_size_host, const int *out_size_host,
+                       const int *filter_host, const int *stride_host, const float *in, int cin,
+                       const float *packed_w, int cout, const float *residual, float *out,
+                       void *stream, double *macs_host);
+
+/* a8. BatchNormalization_updateOutput (SCN/sparseconvnet.h:21-26; SCN/CPU/BatchNormalization.cpp:12-60).
+ * train!=0: batch statistics, running update r = m*r + (1-m)*batch.  train==0: uses
+ * running_mean / running_var.  d3d_bn_batch_stats computes mean(0) and the UNBIASED var(0)
+ * that sparseconvnet/batchNormalization.py:51-56 feeds in when track_running_stats=False.    */
+int d3d_bn_forward(const float *in, float *out, int rows, int planes, float *save_mean,
+                   float *save_invstd, float *running_mean, float *running_var,
+                   const float *weight, const float *bias, float eps, float momentum, int train,
+                   float leakiness, void *scratch, size_t scratch_bytes, void *stream);
+int d3d_bn_batch_stats(const float *in, int rows, int planes, float *mean, float *var_unbiased,
+                       void *scratch, size_t scratch_bytes, void *stream);
+size_t d3d_bn_scratch_bytes(int planes);
+/* sparseconvnet/utils.py:61-66 add_feature_planes / tables.py AddTable: out = a + b. */
+int d3d_add(const float *a, const float *b, float *out, size_t n, void *stream);
+
+/* a20. SparseToDense_updateOutput (SCN/sparseconvnet.h:214-217; SCN/CPU/SparseToDense.cpp:7-60):
+ * zero-filled dense [batch, planes, X, Y, Z].                                                */
+int d3d_sparse_to_dense_forward(d3d_meta *m, const int *spatial_size_host, const float *in,
+                                int planes, int batch, float *out, void *stream);
+
+/* a21. _C.roi_align_rotated_3d_forward (maskrcnn_benchmark/csrc/ROIAlignRotated3D.h:10-26;
+ * csrc/cuda/ROIAlignRotated3D_cuda.cu:89-177).  Dense input [B,C,H,W,Z]; rois [K,8].          */
+int d3d_roi_align_rotated_3d_forward(const float *input, int B, int C, int H, int W, int Z,
+                                     const float *rois, int K, float spatial_scale, int ph, int pw,
+                                     int pz, int sampling_ratio, float *out, void *stream);
+/* Same result sampled straight from the sparse tensor through the hash grid (no 1 GB dense
+ * map): equals sparse_3d_to_dense_2d (sparseconvnet/tools_3d_2d.py:7-48, crop to the occupied
+ * extent crop_host[3]) followed by the dense op.                                             */
+int d3d_roi_align_rotated_3d_sparse_forward(d3d_meta *m, const int *spatial_size_host,
+                                            const float *feats, int C, const int *crop_host,
+                                            const float *rois, int K, float spatial_scale, int ph,
+                                            int pw, int pz, int sampling_ratio, float *out,
+                                            void *stream);
+
+/* a17. rotate_iou_gpu_eval (second/core/non_max_suppression/nms_gpu.py:614-664) incl.
+ * check_same_boxes: boxes [N,5], query [K,5] -> out [N,K].                                   */
+int d3d_rotate_iou_eval(const float *boxes, int N, const float *query, int K, int criterion,
+                        float *out, void *stream);
+/* a16. boxes_iou_3d (utils3d/rotate_nms_3d_torch.py:23-88): targets [M,7], anchors [N,7] yx_zb,
+ * aug_host = {target_Y, target_Z, anchor_Y, anchor_Z}.                                       */
+int d3d_boxes_iou_3d(const float *targets, int M, const float *anchors, int N,
+                     const float *aug_host, int criterion, int only_xy, float *out, void *stream);
+/* a15/a18. rotate_nms_3d_cc (second/core/non_max_suppression/nms_cpu.py:32-44) + spconv's
+ * rotate_non_max_suppression_cpu: boxes [n,7] yx_zb ALREADY sorted by descending score
+ * (the callers top-k first, box_torch_ops.py:495-499).  keep int32 [n] receives positions in
+ * selection order; n_keep (device int32).  scratch >= d3d_nms_scratch_bytes(n).              */
+int d3d_rotate_nms_3d_sorted(const float *boxes, int n, float thresh, int32_t *keep,
+                             int32_t *n_keep, void *scratch, size_t scratch_bytes, void *stream);
+size_t d3d_nms_scratch_bytes(int n);
+/* a14. BoxCoder3D.decode (maskrcnn_benchmark/modeling/box_coder_3d.py:38-65). */
+int d3d_box_decode(const float *enc, const float *anchors, int n, const float *weights_host,
+                   float clip, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D3D_HIP_H */

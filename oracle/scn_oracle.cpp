@@ -1,0 +1,268 @@
+// TEST INFRASTRUCTURE ONLY -- CPU restatement ("port") of the reference's sparse-conv path.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+// library.  The product path (detection_3d_amd/) never links, imports or calls it.
+//
+// PARITY PINNING: the reference's C++ (SparseConvNet/sparseconvnet/SCN) cannot be built in
+// this image: it includes <google/dense_hash_map> (sparsehash), which is not installed, and
+// writing a stand-in header is not allowed.  The reference holds no golden vectors for the
+// sparse-conv path, so this restatement is "parity unpinned" against
+// reference outputs.  It is pinned instead by (i) independent library known answers
+// (torch dense conv3d / conv_transpose3d on densified grids, tests/test_oracle_scn.py) and
+// (ii) analytic cases.  Order-dependent quantities that the reference derives from
+// google::dense_hash_map iteration order (rule order inside one filter offset, numbering of
+// strided-conv output sites) are defined here canonically: iteration in site-id order.
+//
+// All file:line citations are into /root/reference/SparseConvNet/sparseconvnet/SCN/.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+typedef int32_t Int;  // Metadata/32bits.h:11
+
+inline uint64_t pack(Int b, Int x, Int y, Int z) {
+  return ((uint64_t)(uint16_t)b << 48) | ((uint64_t)(uint16_t)x << 32) |
+         ((uint64_t)(uint16_t)y << 16) | (uint64_t)(uint16_t)z;
+}
+}  // namespace
+
+extern "C" {
+
+// Metadata/IOLayersRules.h:19-125 (modes 1..4 share the site numbering at :72-95):
+// site id = first-occurrence order over the input rows, one global counter over all batch
+// samples.  coords: int64 [n, ncols] (x,y,z[,batch]).  Outputs: site_of_point[n],
+// loc[nActive*4] (x,y,z,b) (caller allocates n*4), returns nActive.
+int orc_input_sites(const int64_t *coords, int n, int ncols, int32_t *site_of_point,
+                    int32_t *loc) {
+  std::unordered_map<uint64_t, Int> mp;
+  mp.reserve((size_t)n * 2);
+  Int nActive = 0;
+  for (int i = 0; i < n; i++) {
+    const int64_t *c = coords + (size_t)i * ncols;
+    Int b = ncols == 4 ? (Int)c[3] : 0;
+    uint64_t key = pack(b, (Int)c[0], (Int)c[1], (Int)c[2]);
+    auto it = mp.find(key);
+    if (it == mp.end()) {
+      loc[nActive * 4 + 0] = (Int)c[0];
+      loc[nActive * 4 + 1] = (Int)c[1];
+      loc[nActive * 4 + 2] = (Int)c[2];
+      loc[nActive * 4 + 3] = b;
+      it = mp.emplace(key, nActive++).first;
+    }
+    site_of_point[i] = it->second;
+  }
+  return nActive;
+}
+
+// Rule table of IOLayersRules.h:112-124: rows [count, idx0..idx_{maxActive-1}] in input
+// order.  Call with rules==nullptr to get maxActive; then with rules sized nActive*(1+maxActive).
+int orc_input_rule_table(const int32_t *site_of_point, int n, int nActive, int32_t *rules) {
+  std::vector<Int> cnt(nActive, 0);
+  for (int i = 0; i < n; i++) cnt[site_of_point[i]]++;
+  Int maxActive = 0;
+  for (Int c : cnt) maxActive = std::max(maxActive, c);
+  if (!rules) return maxActive;
+  std::memset(rules, 0, sizeof(int32_t) * (size_t)nActive * (1 + maxActive));
+  for (int i = 0; i < n; i++) {
+    int32_t *r = rules + (size_t)site_of_point[i] * (1 + maxActive);
+    r[1 + r[0]] = i;
+    r[0]++;
+  }
+  return maxActive;
+}
+
+// CPU/IOLayers.cpp:11-29 InputLayer_ForwardPass, mode 3 (sum) / 4 (average):
+// out[row] += multiplier * in[idx] sequentially in input order, multiplier = (T)1/nActive.
+void orc_input_forward(const float *in, int n, int C, const int32_t *site_of_point, int nActive,
+                       int average, float *out) {
+  std::vector<Int> cnt(nActive, 0);
+  for (int i = 0; i < n; i++) cnt[site_of_point[i]]++;
+  std::memset(out, 0, sizeof(float) * (size_t)nActive * C);
+  for (int i = 0; i < n; i++) {
+    Int s = site_of_point[i];
+    float mult = (average && cnt[s] > 0) ? (float)1 / cnt[s] : (float)1;
+    for (int c = 0; c < C; c++) out[(size_t)s * C + c] += mult * in[(size_t)i * C + c];
+  }
+}
+
+// Metadata/SubmanifoldConvolutionRules.h:13-45: for every active output site probe the
+// filter box [out-pad, out+size-1-pad], pad=size/2; offsets enumerated last-dimension-fastest
+// (RectangularRegions.h:31-38,55-69).  Canonical form: outputs visited in site-id order.
+// nbr: int32 [n, K] (input id or -1), K = fx*fy*fz.  Returns the number of rules.
+long orc_subm_nbr(const int32_t *loc, int n, const int *filt, int32_t *nbr) {
+  std::unordered_map<uint64_t, Int> mp;
+  mp.reserve((size_t)n * 2);
+  for (int i = 0; i < n; i++)
+    mp.emplace(pack(loc[i * 4 + 3], loc[i * 4], loc[i * 4 + 1], loc[i * 4 + 2]), i);
+  int K = filt[0] * filt[1] * filt[2];
+  long total = 0;
+  for (int i = 0; i < n; i++) {
+    const int32_t *p = loc + (size_t)i * 4;
+    int k = 0;
+    for (int dx = 0; dx < filt[0]; dx++)
+      for (int dy = 0; dy < filt[1]; dy++)
+        for (int dz = 0; dz < filt[2]; dz++, k++) {
+          Int x = p[0] - filt[0] / 2 + dx, y = p[1] - filt[1] / 2 + dy, z = p[2] - filt[2] / 2 + dz;
+          Int v = -1;
+          if (x >= 0 && y >= 0 && z >= 0) {
+            auto it = mp.find(pack(p[3], x, y, z));
+            if (it != mp.end()) v = it->second;
+          }
+          nbr[(size_t)i * K + k] = v;
+          total += v >= 0;
+        }
+  }
+  return total;
+}
+
+// Metadata/ConvolutionRules.h:12-34 + RectangularRegions.h:96-119.
+// For each input site (canonical: id order) enumerate the covering outputs
+// (OutputRegionCalculator), find-or-insert the output site (first-touch numbering), record
+// the rule at offset inRegion.offset(in).  Outputs: loc_out[<= n*maxOut, 4], rules as
+// triples (in, out, offset) in emission order (cap n*maxOut).  Returns nOut; *n_rules set.
+int orc_conv_rules(const int32_t *loc, int n, const int *filt, const int *stride,
+                   const int *out_size, int32_t *loc_out, int32_t *rules, long *n_rules) {
+  std::unordered_map<uint64_t, Int> mp;
+  mp.reserve((size_t)n * 2);
+  Int nOut = 0;
+  long nr = 0;
+  for (int i = 0; i < n; i++) {
+    const int32_t *p = loc + (size_t)i * 4;
+    long lb[3], ub[3];
+    for (int d = 0; d < 3; d++) {
+      lb[d] = std::max(0L, ((long)p[d] - filt[d] + stride[d]) / stride[d]);
+      ub[d] = std::min((long)out_size[d] - 1, (long)p[d] / stride[d]);
+    }
+    for (long ox = lb[0]; ox <= ub[0]; ox++)
+      for (long oy = lb[1]; oy <= ub[1]; oy++)
+        for (long oz = lb[2]; oz <= ub[2]; oz++) {
+          // InputRegionCalculator(j).offset(in), RectangularRegions.h:31-38
+          long off = ((p[0] - ox * stride[0]) * filt[1] + (p[1] - oy * stride[1])) * filt[2] +
+                     (p[2] - oz * stride[2]);
+          uint64_t key = pack(p[3], (Int)ox, (Int)oy, (Int)oz);
+          auto it = mp.find(key);
+          if (it == mp.end()) {
+            loc_out[nOut * 4 + 0] = (Int)ox;
+            loc_out[nOut * 4 + 1] = (Int)oy;
+            loc_out[nOut * 4 + 2] = (Int)oz;
+            loc_out[nOut * 4 + 3] = p[3];
+            it = mp.emplace(key, nOut++).first;
+          }
+          rules[nr * 3 + 0] = i;
+          rules[nr * 3 + 1] = it->second;
+          rules[nr * 3 + 2] = (Int)off;
+          nr++;
+        }
+  }
+  *n_rules = nr;
+  return nOut;
+}
+
+// CPU/Convolution.cpp:46-79 (cpu_Convolution_updateOutput), :117-150 (submanifold) and
+// CPU/Deconvolution.cpp:7-41: out = 0; for each filter offset k in order, for each rule of k:
+// out[r_out] += in[r_in] @ W[k].  groups==1, no bias (fpn_net.py builds every conv with
+// bias=False).  rules: triples (in,out,offset); processed grouped by offset, stable.
+// The per-rule dot product is accumulated in double (the CUDA reference's TACC,
+// CUDA/Convolution.cu:8) and added to the fp32 output once per offset.
+void orc_rule_conv(const float *in, int Cin, const float *W, int K, int Cout,
+                   const int32_t *rules, long n_rules, float *out, int n_out) {
+  std::memset(out, 0, sizeof(float) * (size_t)n_out * Cout);
+  std::vector<std::vector<long>> by_off(K);
+  for (long r = 0; r < n_rules; r++) by_off[rules[r * 3 + 2]].push_back(r);
+  for (int k = 0; k < K; k++) {
+    const float *Wk = W + (size_t)k * Cin * Cout;
+    const auto &lst = by_off[k];
+#pragma omp parallel for schedule(static)
+    for (long t = 0; t < (long)lst.size(); t++) {
+      long r = lst[t];
+      const float *x = in + (size_t)rules[r * 3] * Cin;
+      float *y = out + (size_t)rules[r * 3 + 1] * Cout;
+      for (int co = 0; co < Cout; co++) {
+        double acc = 0;
+        for (int ci = 0; ci < Cin; ci++) acc += (double)x[ci] * (double)Wk[(size_t)ci * Cout + co];
+        y[co] += (float)acc;
+      }
+    }
+  }
+}
+
+// Same contraction through a neighbour table (submanifold form): out[i] = sum_k in[nbr[i,k]] W[k].
+void orc_nbr_conv(const float *in, int Cin, const float *W, int K, int Cout, const int32_t *nbr,
+                  float *out, int n_out) {
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n_out; i++) {
+    float *y = out + (size_t)i * Cout;
+    for (int co = 0; co < Cout; co++) y[co] = 0.f;
+    for (int k = 0; k < K; k++) {
+      int j = nbr[(size_t)i * K + k];
+      if (j < 0) continue;
+      const float *x = in + (size_t)j * Cin;
+      const float *Wk = W + (size_t)k * Cin * Cout;
+      for (int co = 0; co < Cout; co++) {
+        double acc = 0;
+        for (int ci = 0; ci < Cin; ci++) acc += (double)x[ci] * (double)Wk[(size_t)ci * Cout + co];
+        y[co] += (float)acc;
+      }
+    }
+  }
+}
+
+// CPU/BatchNormalization.cpp:12-60 BatchNormalization_ForwardPass, line by line.
+void orc_bn_forward(const float *in, float *out, int nPlanes, int nActive, float *saveMean,
+                    float *saveInvStd, float *runningMean, float *runningVar,
+                    const float *weight, const float *bias, float eps, float momentum, int train,
+                    float leakiness) {
+  if (train) {
+    std::memset(saveMean, 0, nPlanes * sizeof(float));
+    std::memset(saveInvStd, 0, nPlanes * sizeof(float));
+    for (int row = 0; row < nActive; row++)
+      for (int p = 0; p < nPlanes; p++) {
+        float v = in[(size_t)row * nPlanes + p];
+        saveMean[p] += v;
+        saveInvStd[p] += v * v;
+      }
+    for (int p = 0; p < nPlanes; p++) {
+      saveMean[p] /= nActive;
+      runningMean[p] = momentum * runningMean[p] + (1 - momentum) * saveMean[p];
+      saveInvStd[p] -= saveMean[p] * saveMean[p] * nActive;
+      runningVar[p] = momentum * runningVar[p] + (1 - momentum) * saveInvStd[p] / (nActive - 1);
+      saveInvStd[p] = powf(saveInvStd[p] / nActive + eps, -0.5);
+    }
+  } else {
+    for (int p = 0; p < nPlanes; p++) {
+      saveMean[p] = runningMean[p];
+      saveInvStd[p] = powf(runningVar[p] + eps, -0.5);
+    }
+  }
+  std::vector<float> w(nPlanes), b(nPlanes);
+  for (int p = 0; p < nPlanes; p++) {
+    w[p] = saveInvStd[p] * (weight ? weight[p] : 1);
+    b[p] = -saveMean[p] * w[p] + (bias ? bias[p] : 0);
+  }
+  for (int row = 0; row < nActive; row++)
+    for (int p = 0; p < nPlanes; p++) {
+      float o = in[(size_t)row * nPlanes + p] * w[p] + b[p];
+      const float r = (o > 0) ? 1 : leakiness;
+      out[(size_t)row * nPlanes + p] = o * r;
+    }
+}
+
+// CPU/SparseToDense.cpp:7-20 + Metadata/ConvolutionRules.h:110-131: dense [B, C, X, Y, Z],
+// zero-filled, row i scattered to channel stride X*Y*Z at offset (x*Y + y)*Z + z.
+void orc_sparse_to_dense(const float *in, int C, const int32_t *loc, int n, const int *size,
+                         int batch, float *out) {
+  size_t vol = (size_t)size[0] * size[1] * size[2];
+  std::memset(out, 0, sizeof(float) * vol * C * batch);
+  for (int i = 0; i < n; i++) {
+    const int32_t *p = loc + (size_t)i * 4;
+    size_t off = ((size_t)p[0] * size[1] + p[1]) * size[2] + p[2];
+    float *o = out + (size_t)p[3] * C * vol + off;
+    for (int c = 0; c < C; c++) o[(size_t)c * vol] = in[(size_t)i * C + c];
+  }
+}
+
+}  // extern "C"

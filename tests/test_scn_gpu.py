@@ -1,0 +1,206 @@
+"""GPU parity tests of the sparse-conv path: HIP (through the C ABI / host mirror) vs the CPU
+oracle on the same seeded inputs.  Integer results (site ids, point lists, rulebooks, coarse
+grids) are compared bit-exactly; fp32 features within 1e-4 relative (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from tests.helpers import OracleFPN, canon_rules, nbr_to_rules, small_scene, sort_by_loc
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def _input(dev, coords, feats, size):
+    from detection_3d_amd import sparseconvnet as scn
+    layer = scn.InputLayer(3, size, mode=4)
+    return layer([torch.from_numpy(coords), torch.from_numpy(feats).to(dev)])
+
+
+@pytest.mark.parametrize("n_points,extent,size", [
+    (3000, (1.2, 1.0, 0.3), (64, 64, 16)),
+    (40000, (5.0, 4.0, 0.6), (256, 256, 32)),
+])
+def test_input_layer_exact(dev, n_points, extent, size):
+    _, coords, feats = small_scene(1, n_points, extent, size)
+    t = _input(dev, coords, feats, size)
+    sop, loc = oracle.input_sites(coords)
+    got_loc = t.get_spatial_locations().cpu().numpy()
+    assert got_loc.shape[0] == loc.shape[0]
+    assert np.array_equal(got_loc, loc.astype(np.int64))          # first-occurrence ids, exact
+    off, idx = t.metadata.export_input_rules(coords.shape[0])
+    rules = oracle.input_rule_table(sop, loc.shape[0])
+    off, idx = off.cpu().numpy(), idx.cpu().numpy()
+    assert np.array_equal(np.diff(off), rules[:, 0])
+    for r in np.random.RandomState(0).randint(0, loc.shape[0], 200):
+        assert np.array_equal(idx[off[r]:off[r + 1]], rules[r, 1:1 + rules[r, 0]])
+    want = oracle.input_forward(feats, sop, loc.shape[0], True)
+    assert np.array_equal(t.features.cpu().numpy(), want)          # same fp32 op order -> bit exact
+
+
+def test_input_layer_duplicates_and_batch(dev):
+    # many points per voxel + two batch samples (ragged): ids global over samples
+    rng = np.random.RandomState(3)
+    c0 = rng.randint(0, 6, (500, 3))
+    c1 = rng.randint(0, 6, (137, 3))
+    coords = np.concatenate([np.concatenate([c0, np.zeros((500, 1), int)], 1),
+                             np.concatenate([c1, np.ones((137, 1), int)], 1)]).astype(np.int64)
+    feats = rng.randn(637, 9).astype(np.float32)
+    t = _input(dev, coords, feats, (8, 8, 8))
+    sop, loc = oracle.input_sites(coords)
+    assert np.array_equal(t.get_spatial_locations().cpu().numpy(), loc.astype(np.int64))
+    want = oracle.input_forward(feats, sop, loc.shape[0], True)
+    assert np.array_equal(t.features.cpu().numpy(), want)
+
+
+def test_rulebooks_exact(dev):
+    size = (256, 256, 32)
+    _, coords, feats = small_scene(2, 40000, (5.0, 4.0, 0.6), size)
+    t = _input(dev, coords, feats, size)
+    m = t.metadata
+    from detection_3d_amd._lib import check, ints, lib, stream_of
+    import ctypes
+    _, loc = oracle.input_sites(coords)
+    # submanifold 3x3x3 and 1x1x1
+    for filt in ([3, 3, 3], [1, 1, 1]):
+        nr = ctypes.c_long(0)
+        check(lib().d3d_subm_prepare(m._h, ints(size), ints(filt), stream_of(), ctypes.byref(nr)))
+        nbr, total = oracle.subm_nbr(loc, filt)
+        assert nr.value == total
+        got = canon_rules(m.export_rules(0, size, filt).cpu().numpy())
+        assert np.array_equal(got, canon_rules(nbr_to_rules(nbr)))
+    # strided 2/2 chain and the [1,1,Z] projection
+    cur_size, cur_loc = list(size), loc
+    for _ in range(3):
+        out_size = [s // 2 for s in cur_size]
+        n_out = ctypes.c_int(0)
+        nr = ctypes.c_long(0)
+        check(lib().d3d_conv_prepare(m._h, ints(cur_size), ints(out_size), ints([2, 2, 2]), ints([2, 2, 2]),
+                                     stream_of(), ctypes.byref(n_out), ctypes.byref(nr)))
+        lo, ru = oracle.conv_rules(cur_loc, [2, 2, 2], [2, 2, 2], out_size)
+        assert n_out.value == lo.shape[0] and nr.value == ru.shape[0]
+        got_loc = m.getSpatialLocations(out_size).cpu().numpy()
+        assert np.array_equal(got_loc, lo.astype(np.int64))       # canonical first-touch numbering
+        got = canon_rules(m.export_rules(1, cur_size, [2, 2, 2], [2, 2, 2]).cpu().numpy())
+        assert np.array_equal(got, canon_rules(ru))
+        cur_size, cur_loc = out_size, lo
+    z = cur_size[2]
+    out_size = [cur_size[0], cur_size[1], 1]
+    n_out = ctypes.c_int(0)
+    check(lib().d3d_conv_prepare(m._h, ints(cur_size), ints(out_size), ints([1, 1, z]), ints([1, 1, 1]),
+                                 stream_of(), ctypes.byref(n_out), None))
+    lo, ru = oracle.conv_rules(cur_loc, [1, 1, z], [1, 1, 1], out_size)
+    assert n_out.value == lo.shape[0]
+    assert np.array_equal(m.getSpatialLocations(out_size).cpu().numpy(), lo.astype(np.int64))
+    got = canon_rules(m.export_rules(1, cur_size, [1, 1, z], [1, 1, 1]).cpu().numpy())
+    assert np.array_equal(got, canon_rules(ru))
+
+
+@pytest.mark.parametrize("cin,cout", [(9, 32), (32, 32), (64, 64), (64, 128), (128, 128), (256, 128), (128, 256)])
+def test_conv_ops(dev, cin, cout):
+    from detection_3d_amd import sparseconvnet as scn
+    size = (64, 64, 16)
+    rng = np.random.RandomState(cin * 1000 + cout)
+    _, coords, _ = small_scene(4, 6000, (1.2, 1.0, 0.3), size)
+    feats = rng.randn(coords.shape[0], cin).astype(np.float32)
+    layer = scn.InputLayer(3, size, mode=4)
+    t = layer([torch.from_numpy(coords), torch.from_numpy(feats).to(dev)])
+    sop, loc = oracle.input_sites(coords)
+    x = oracle.input_forward(feats, sop, loc.shape[0], True)
+    torch.manual_seed(0)
+    # submanifold 3^3 (+ fused residual)
+    conv = scn.SubmanifoldConvolution(3, cin, cout, 3, False).to(dev)
+    res = torch.randn(loc.shape[0], cout, device=dev)
+    got = conv(t).features.cpu().numpy()
+    got_res = conv(t, residual=scn.SparseConvNetTensor(res, t.metadata, t.spatial_size)).features.cpu().numpy()
+    w = conv.weight.detach().cpu().numpy().reshape(27, cin, cout)
+    nbr, _ = oracle.subm_nbr(loc, [3, 3, 3])
+    want = oracle.nbr_conv(x, w, nbr)
+    assert rel_err(got, want) < RTOL
+    assert rel_err(got_res, want + res.cpu().numpy()) < RTOL
+    # strided 2/2 and its deconvolution
+    down = scn.Convolution(3, cin, cout, [2, 2, 2], [2, 2, 2], False).to(dev)
+    d = down(t)
+    lo, ru = oracle.conv_rules(loc, [2, 2, 2], [2, 2, 2], [32, 32, 8])
+    wd = down.weight.detach().cpu().numpy().reshape(8, cin, cout)
+    want_d = oracle.rule_conv(x, wd, ru, lo.shape[0])
+    assert np.array_equal(d.get_spatial_locations().cpu().numpy(), lo.astype(np.int64))
+    assert rel_err(d.features.cpu().numpy(), want_d) < RTOL
+    up = scn.Deconvolution(3, cout, cin if cin % 32 == 0 else 32, [2, 2, 2], [2, 2, 2], False).to(dev)
+    u = up(d)
+    wu = up.weight.detach().cpu().numpy().reshape(8, cout, -1)
+    want_u = oracle.rule_conv(want_d, wu, ru, loc.shape[0], deconv=True)
+    assert u.features.shape[0] == loc.shape[0]
+    assert rel_err(u.features.cpu().numpy(), want_u) < RTOL
+
+
+def test_batchnorm(dev):
+    from detection_3d_amd import sparseconvnet as scn
+    rng = np.random.RandomState(5)
+    for C in (32, 64, 128, 256):
+        x = (rng.randn(5000, C) * 2 + 0.5).astype(np.float32)
+        t = scn.SparseConvNetTensor(torch.from_numpy(x).to(dev), None, torch.tensor([8, 8, 8]))
+        # eval, batch statistics (TRACK_RUNNING_STATS False)
+        bn = scn.BatchNormLeakyReLU(C, momentum=0.95, leakiness=0, track_running_stats=False).to(dev).eval()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.5, 0.5)
+        got = bn(t).features.cpu().numpy()
+        mean = x.mean(0, dtype=np.float64).astype(np.float32)
+        var = x.var(0, ddof=1, dtype=np.float64).astype(np.float32)
+        want, *_ = oracle.bn_forward(x, mean, var, bn.weight.detach().cpu().numpy(),
+                                     bn.bias.detach().cpu().numpy(), 1e-4, 0.95, False, 0.0)
+        assert np.abs(got - want).max() < 1e-4 * max(1.0, np.abs(want).max())
+        # train mode: running statistics update (retention momentum)
+        bn2 = scn.BatchNormLeakyReLU(C, momentum=0.95, leakiness=0.333).to(dev).train()
+        got2 = bn2(t).features.cpu().numpy()
+        want2, sm, si, rm, rv = oracle.bn_forward(x, np.zeros(C), np.ones(C), np.ones(C), np.zeros(C),
+                                                  1e-4, 0.95, True, 0.333)
+        assert np.abs(got2 - want2).max() < 2e-4 * max(1.0, np.abs(want2).max())
+        assert np.allclose(bn2.running_mean.cpu().numpy(), rm, rtol=1e-4, atol=1e-6)
+        assert np.allclose(bn2.running_var.cpu().numpy(), rv, rtol=1e-4, atol=1e-6)
+
+
+def test_sparse_to_dense(dev):
+    from detection_3d_amd import sparseconvnet as scn
+    size = (32, 32, 8)
+    _, coords, feats = small_scene(6, 2000, (0.6, 0.6, 0.15), size)
+    t = _input(dev, coords, feats, size)
+    dense = scn.SparseToDense(3, 9)(t, batch_size=1).cpu().numpy()
+    sop, loc = oracle.input_sites(coords)
+    want = oracle.sparse_to_dense(oracle.input_forward(feats, sop, loc.shape[0], True), loc, size, 1)
+    assert np.array_equal(dense, want)
+
+
+def _mini_fpn(dev, fuse, skip):
+    from detection_3d_amd import sparseconvnet as scn
+    torch.manual_seed(0)
+    net = scn.FPN_Net([256, 256, 32], 3, ['xyz', 'color', 'normal'], 1, [32, 64, 64, 128, 128], nPlaneM=128,
+                      residual_blocks=True, fpn_scales_from_top=[2, 1], roi_scales_from_top=(2, 1),
+                      downsample=[[[2, 2, 2]] * 4] * 2, rpn_map_sizes=[[64, 64, 8], [32, 32, 4]],
+                      voxel_scale=50, rpn_3d_2d_selector=[1, 2, 3], bn_momentum=0.95,
+                      track_running_stats=False, fuse_adds=fuse, skip_unused=skip)
+    return net.to(dev).eval()
+
+
+@pytest.mark.parametrize("fuse,skip", [(True, True), (False, False)])
+def test_fpn_backbone_vs_oracle(dev, fuse, skip):
+    size = (256, 256, 32)
+    _, coords, feats = small_scene(7, 60000, (5.0, 4.0, 0.6), size)
+    net = _mini_fpn(dev, fuse, skip)
+    rpn, roi = net([torch.from_numpy(coords), torch.from_numpy(feats).to(dev)])
+    orc = OracleFPN(net.state_dict(), size, 5, [2, 1], [2, 1], [1, 2, 3])
+    rpn_w, roi_w = orc(coords, feats)
+    for got, (wf, wl) in list(zip(rpn, rpn_w)) + list(zip(roi, roi_w)):
+        gl = got.get_spatial_locations().cpu().numpy()
+        gf, gl = sort_by_loc(got.features.cpu().numpy(), gl)
+        wf, wl = sort_by_loc(wf, wl)
+        assert np.array_equal(gl, wl.astype(np.int64))
+        assert rel_err(gf, wf) < 2e-4, rel_err(gf, wf)
