@@ -1,0 +1,141 @@
+"""Rotated IoU / NMS / box codec ops with the reference's Python-level names and argument meaning,
+running entirely on the GPU through libd3d_hip.so (no numpy / numba / spconv round trips).
+
+    rotate_iou_gpu_eval   second/core/non_max_suppression/nms_gpu.py:614-650
+    boxes_iou_3d          utils3d/rotate_nms_3d_torch.py:23-88
+    rotate_nms_3d         second/pytorch/core/box_torch_ops.py:489-514
+    nms_3d_clamped        maskrcnn_benchmark/structures/boxlist_ops_3d.py:14-62 (tensor form)
+    box_decode            maskrcnn_benchmark/modeling/box_coder_3d.py:38-65
+    limit_period          utils3d/geometric_torch.py:4-10
+"""
+import math
+
+import torch
+
+from ._lib import D3DError, check, floats, lib, ptr, require_gpu, stream_of
+
+
+def limit_period(val, offset, period):
+    return val - torch.floor(val / period + offset) * period
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def rotate_iou_gpu_eval(boxes, query_boxes, criterion=-1, device_id=0):
+    """boxes [N,5], query_boxes [K,5] (xc, yc, d0, d1, angle) -> iou [N,K] (torch, on the GPU).
+    Includes check_same_boxes (nms_gpu.py:653-664)."""
+    boxes, query_boxes = _f32c(boxes), _f32c(query_boxes)
+    require_gpu(boxes, query_boxes)
+    n, k = boxes.shape[0], query_boxes.shape[0]
+    out = torch.zeros((n, k), dtype=torch.float32, device=boxes.device)
+    if n and k:
+        check(lib().d3d_rotate_iou_eval(ptr(boxes), n, ptr(query_boxes), k, int(criterion), ptr(out),
+                                        stream_of()))
+    return out
+
+
+_FLAG_RULES = {
+    # flag -> checker(aug) reproducing the asserts of rotate_nms_3d_torch.py:32-48
+    "rpn_label_generation": lambda a: a["anchor_Y"] == 0 and a["target_Y"] >= 0.3,
+    "roi_label_generation": lambda a: a["anchor_Y"] >= 0.3 and a["target_Y"] >= 0.3,
+    "eval": lambda a: a["anchor_Y"] <= 0.3 and a["target_Y"] <= 0.3,
+}
+
+
+def boxes_iou_3d(targets_bbox3d, anchors_bbox3d, aug_thickness=None, criterion=-1, only_xy=False, flag=''):
+    """targets [M,7], anchors [N,7] in yx_zb mode -> iou3d [M,N] = BEV rotated IoU x z-interval IoU."""
+    if flag in _FLAG_RULES:
+        assert _FLAG_RULES[flag](aug_thickness), (flag, aug_thickness)
+    elif flag in ("rpn_post", "roi_post"):
+        assert aug_thickness is None
+    else:
+        raise NotImplementedError(f"boxes_iou_3d: unknown flag {flag!r}")
+    if aug_thickness is None:
+        aug_thickness = {'target_Y': 0.0, 'target_Z': 0.0, 'anchor_Y': 0.0, 'anchor_Z': 0.0}
+    t, a = _f32c(targets_bbox3d), _f32c(anchors_bbox3d)
+    require_gpu(t, a)
+    m, n = t.shape[0], a.shape[0]
+    out = torch.zeros((m, n), dtype=torch.float32, device=t.device)
+    if m and n:
+        aug = floats([aug_thickness['target_Y'], aug_thickness['target_Z'], aug_thickness['anchor_Y'],
+                      aug_thickness['anchor_Z']])
+        check(lib().d3d_boxes_iou_3d(ptr(t), m, ptr(a), n, aug, int(criterion), int(bool(only_xy)), ptr(out),
+                                     stream_of()))
+    return out
+
+
+_NMS_SCRATCH = {}
+
+
+def _nms_sorted(boxes_sorted, thresh):
+    n = boxes_sorted.shape[0]
+    dev = boxes_sorted.device
+    nbytes = lib().d3d_nms_scratch_bytes(n)
+    buf = _NMS_SCRATCH.get(dev.index)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        _NMS_SCRATCH[dev.index] = buf
+    keep = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    nk = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(lib().d3d_rotate_nms_3d_sorted(ptr(boxes_sorted), n, float(thresh), ptr(keep), ptr(nk), ptr(buf),
+                                         buf.numel(), stream_of()))
+    return keep, nk
+
+
+def rotate_nms_3d(rbboxes, scores, pre_max_size=None, post_max_size=None, iou_threshold=0.5, flag=''):
+    """rbboxes [n,7] yx_zb, scores [n] -> LongTensor of kept indices into the input, in score order."""
+    rbboxes, scores = _f32c(rbboxes), _f32c(scores)
+    require_gpu(rbboxes, scores)
+    if rbboxes.shape[0] == 0:
+        return torch.zeros([0], dtype=torch.int64, device=rbboxes.device)
+    k = scores.shape[0] if pre_max_size is None else min(scores.shape[0], pre_max_size)
+    if k > 4096:
+        raise D3DError("rotate_nms_3d: more than 4096 candidates; pass pre_max_size (reference uses 2000)")
+    # descending score order; ties -> lower index first (stable), same rule as the oracle
+    order = torch.sort(scores, descending=True, stable=True)[1][:k]
+    keep, nk = _nms_sorted(rbboxes[order].contiguous(), iou_threshold)
+    n_keep = int(nk.item())
+    if post_max_size is not None:
+        n_keep = min(n_keep, post_max_size)
+    return order[keep[:n_keep].long()]
+
+
+def nms_3d_clamped(bbox3d, scores, nms_thresh, nms_aug_thickness=None, max_proposals=-1, flag=''):
+    """Tensor form of boxlist_nms_3d: clamps dy,dx >= aug[0] and dz >= aug[1] for the IoU only, keeps
+    pre_max 2000, returns kept indices."""
+    if nms_aug_thickness is None:
+        nms_aug_thickness = [0, 0]
+    if flag == 'rpn_post':
+        assert max_proposals > 100, max_proposals
+    elif flag == 'roi_post':
+        assert max_proposals == -1
+    else:
+        raise NotImplementedError(flag)
+    if max_proposals < 0:
+        max_proposals = 500
+    b = bbox3d.clone().detach()
+    b[:, 3:5] = torch.clamp(b[:, 3:5], min=nms_aug_thickness[0])
+    b[:, 5] = torch.clamp(b[:, 5], min=nms_aug_thickness[1])
+    return rotate_nms_3d(b, scores, pre_max_size=2000, post_max_size=max_proposals,
+                         iou_threshold=nms_thresh, flag=flag)
+
+
+def box_decode(box_encodings, anchors, weights=(1.0,) * 7, bbox_xform_clip=10000.0):
+    """BoxCoder3D.decode with smooth_dim=True; box_encodings [n, 7*nc], anchors [n, 7]."""
+    enc, anc = _f32c(box_encodings), _f32c(anchors)
+    require_gpu(enc, anc)
+    assert enc.shape[0] == anc.shape[0] and anc.shape[1] == 7
+    nc = enc.shape[1] // 7
+    if nc != 1:
+        n = enc.shape[0]
+        enc = enc.view(-1, 7)
+        anc = anc.view(n, 1, 7).repeat(1, nc, 1).view(-1, 7).contiguous()
+    out = torch.empty_like(enc)
+    if enc.shape[0]:
+        check(lib().d3d_box_decode(ptr(enc), ptr(anc), enc.shape[0], floats(weights), float(bbox_xform_clip),
+                                   ptr(out), stream_of()))
+    if nc != 1:
+        out = out.view(-1, nc * 7)
+    return out

@@ -177,6 +177,17 @@ def rotate_iou_eval(boxes, query, criterion=-1):
     return out
 
 
+def rotate_iou_raw(boxes, query, criterion=-1, eps_variant=False):
+    """rotate_iou_gpu_eval without check_same_boxes; eps_variant=True additionally uses the
+    commented-out tolerance predicate of nms_gpu.py:326-327 (pins test_nms_gpu.py:14-15)."""
+    boxes = _f32(boxes)
+    query = _f32(query)
+    out = np.zeros((boxes.shape[0], query.shape[0]), np.float32)
+    lib().orc_rotate_iou_raw(_p(boxes), boxes.shape[0], _p(query), query.shape[0], int(criterion),
+                             int(eps_variant), _p(out))
+    return out
+
+
 def boxes_iou_3d(targets, anchors, aug=None, criterion=-1, only_xy=False):
     """aug = dict(target_Y, target_Z, anchor_Y, anchor_Z) or None."""
     targets = _f32(targets)

@@ -112,7 +112,10 @@ bool line_segment_intersection(const float *pts1, const float *pts2, int i, int 
   return false;
 }
 
-// nms_gpu.py:310-328
+// nms_gpu.py:310-328.  g_eps_variant selects the commented-out tolerance form of :326-327
+// (`eps = -1e-6`), the code state in which the values recorded in test_nms_gpu.py:14-15 were
+// printed; it is used by orc_rotate_iou_raw only.
+bool g_eps_variant = false;
 bool point_in_quadrilateral(float pt_x, float pt_y, const float *corners) {
   float ab0 = corners[2] - corners[0], ab1 = corners[3] - corners[1];
   float ad0 = corners[6] - corners[0], ad1 = corners[7] - corners[1];
@@ -121,6 +124,10 @@ bool point_in_quadrilateral(float pt_x, float pt_y, const float *corners) {
   float abap = ab0 * ap0 + ab1 * ap1;
   float adad = ad0 * ad0 + ad1 * ad1;
   float adap = ad0 * ap0 + ad1 * ap1;
+  if (g_eps_variant) {
+    const float eps = -1e-6f;
+    return abab - abap >= eps && abap >= eps && adad - adap >= eps && adap >= eps;
+  }
   return abab >= abap && abap >= 0 && adad >= adap && adap >= 0;
 }
 
@@ -265,6 +272,17 @@ void orc_rotate_iou_eval(const float *boxes, int N, const float *query, int K, i
         same = same && (std::fabs(boxes[5 * n + d] - query[5 * k + d]) < (float)1e-6);
       out[(size_t)n * K + k] = same ? 1.f : v;
     }
+}
+
+// Same without the check_same_boxes override: the state of the code when the values recorded in
+// second/core/non_max_suppression/test_nms_gpu.py:14-15 were printed.
+void orc_rotate_iou_raw(const float *boxes, int N, const float *query, int K, int criterion,
+                        int eps_variant, float *out) {
+  g_eps_variant = eps_variant != 0;
+  for (int n = 0; n < N; n++)
+    for (int k = 0; k < K; k++)
+      out[(size_t)n * K + k] = devRotateIoUEval(query + 5 * k, boxes + 5 * n, criterion);
+  g_eps_variant = false;
 }
 
 // boxes_iou_3d (utils3d/rotate_nms_3d_torch.py:23-88) + iou_one_dim (:7-21).

@@ -1,0 +1,157 @@
+"""GPU parity of the box ops vs the oracle.  IoU: the HIP kernels follow the same arithmetic
+contract (fp32 geometry, fp64 fan sum, -ffp-contract=off) and are compared bit-exactly where both
+sides are IEEE basic ops, else within 1e-4 relative (BASELINE.json).  NMS survivor sets: exact."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from detection_3d_amd.synthetic import make_boxes
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _close(got, want, tol=1e-4):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    return np.abs(got - want).max() <= tol * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("criterion", [-1, 0, 1, 2, 3])
+def test_rotate_iou_eval(dev, criterion):
+    from detection_3d_amd import box_ops
+    b, _ = make_boxes(0, 300)
+    q, _ = make_boxes(1, 170)
+    b2, q2 = b[:, [0, 1, 3, 4, 6]], q[:, [0, 1, 3, 4, 6]]
+    q2[:17] = b2[:17]                                            # identical pairs -> forced to 1
+    got = box_ops.rotate_iou_gpu_eval(torch.from_numpy(b2).to(dev), torch.from_numpy(q2).to(dev), criterion).cpu().numpy()
+    want = oracle.rotate_iou_eval(b2, q2, criterion)
+    assert got.shape == (300, 170)
+    assert np.mean(got != want) < 1e-3 and _close(got, want)       # bit-exact but for libm last-ulp cases
+    if criterion == -1:
+        assert np.all(np.diag(got)[:17] == 1.0)
+
+
+def test_empty_and_ragged_shapes(dev):
+    from detection_3d_amd import box_ops
+    e = torch.zeros((0, 5), device=dev)
+    b = torch.from_numpy(make_boxes(0, 65)[0][:, [0, 1, 3, 4, 6]]).to(dev)
+    assert box_ops.rotate_iou_gpu_eval(e, b).shape == (0, 65)
+    assert box_ops.rotate_iou_gpu_eval(b, e).shape == (65, 0)
+    assert box_ops.rotate_nms_3d(torch.zeros((0, 7), device=dev), torch.zeros(0, device=dev), 2000, 100, 0.5).numel() == 0
+    one = torch.from_numpy(make_boxes(0, 1)[0]).to(dev)
+    assert box_ops.rotate_nms_3d(one, torch.ones(1, device=dev), 2000, 100, 0.5).tolist() == [0]
+
+
+def test_boxes_iou_3d_flags(dev):
+    from detection_3d_amd import box_ops
+    t, _ = make_boxes(2, 97)
+    a, _ = make_boxes(3, 1030)
+    tt, aa = torch.from_numpy(t).to(dev), torch.from_numpy(a).to(dev)
+    for flag, aug, crit in [("rpn_post", None, -1),
+                            ("rpn_label_generation", dict(target_Y=0.3, target_Z=0.25, anchor_Y=0.0, anchor_Z=0.0), 2),
+                            ("roi_label_generation", dict(target_Y=0.3, target_Z=0.3, anchor_Y=0.3, anchor_Z=0.3), -1),
+                            ("eval", dict(target_Y=0.2, target_Z=0.2, anchor_Y=0.2, anchor_Z=0.2), -1)]:
+        got = box_ops.boxes_iou_3d(tt, aa, aug, crit, flag=flag).cpu().numpy()
+        want = oracle.boxes_iou_3d(t, a, aug, crit)
+        assert np.mean(got != want) < 1e-3 and _close(got, want), flag
+    with pytest.raises(NotImplementedError):
+        box_ops.boxes_iou_3d(tt, aa, None, -1, flag="bogus")
+
+
+@pytest.mark.parametrize("n,thr,aug", [(2000, 0.5, (0.3, 0.3)), (1000, 0.45, (0.2, 0.2)), (333, 0.3, (0, 0))])
+def test_nms_survivor_sets_exact(dev, n, thr, aug):
+    from detection_3d_amd import box_ops
+    b, s = make_boxes(10 + n, n)
+    s[::7] = s[3]                                                # score ties -> lower index first
+    keep = box_ops.nms_3d_clamped(torch.from_numpy(b).to(dev), torch.from_numpy(s).to(dev), thr, list(aug),
+                                  max_proposals=1000 if n == 2000 else -1,
+                                  flag="rpn_post" if n == 2000 else "roi_post").cpu().numpy()
+    bc = b.copy()
+    bc[:, 3:5] = np.maximum(bc[:, 3:5], aug[0])
+    bc[:, 5] = np.maximum(bc[:, 5], aug[1])
+    want = oracle.rotate_nms_3d(bc, s, thr)[:1000 if n == 2000 else 500]
+    assert np.array_equal(keep, want)
+    assert len(keep) < n                                         # something was suppressed
+
+
+def test_nms_on_reference_demo_detections(dev):
+    from detection_3d_amd import box_ops
+    r = np.load(os.path.join(GOLD, "rooms.npz"))
+    for k in sorted(r.files):
+        s = r[k]
+        b = s[:, [0, 1, 2, 4, 3, 5, 6]].copy()
+        b[:, 2] -= s[:, 5] * 0.5
+        b[:, 6] -= math.pi * 0.5
+        b[:, 6] = b[:, 6] - np.floor(b[:, 6] / math.pi + 0.5) * math.pi
+        b = b.astype(np.float32)
+        for c in np.unique(s[:, 7]):
+            bc = b[s[:, 7] == c]
+            sc = np.linspace(1, 0.5, bc.shape[0]).astype(np.float32)
+            got = box_ops.nms_3d_clamped(torch.from_numpy(bc).to(dev), torch.from_numpy(sc).to(dev), 0.45,
+                                         [0.2, 0.2], -1, flag="roi_post").cpu().numpy()
+            bb = bc.copy()
+            bb[:, 3:5] = np.maximum(bb[:, 3:5], 0.2)
+            bb[:, 5] = np.maximum(bb[:, 5], 0.2)
+            assert np.array_equal(got, oracle.rotate_nms_3d(bb, sc, 0.45))
+
+
+def test_box_decode(dev):
+    from detection_3d_amd import box_ops
+    g = np.load(os.path.join(GOLD, "ref_python.npz"))
+    rng = np.random.RandomState(0)
+    anchors = np.concatenate([rng.rand(4096, 3) * 20, 0.2 + rng.rand(4096, 3) * 3, (rng.rand(4096, 1) - 0.5) * 3], 1).astype(np.float32)
+    enc = (rng.randn(4096, 7) * 0.3).astype(np.float32)
+    enc[:, 6] = g["lp_in"]
+    got = box_ops.box_decode(torch.from_numpy(enc).to(dev), torch.from_numpy(anchors).to(dev)).cpu().numpy()
+    want = oracle.box_decode(enc, anchors)
+    assert np.array_equal(got, want)                             # IEEE basic ops + sqrt + floor only
+    # multi-class layout [n, 7*nc] (box_coder_3d.py:50-63)
+    enc3 = (rng.randn(100, 21) * 0.3).astype(np.float32)
+    got3 = box_ops.box_decode(torch.from_numpy(enc3).to(dev), torch.from_numpy(anchors[:100]).to(dev)).cpu().numpy()
+    for c in range(3):
+        assert np.array_equal(got3[:, 7 * c:7 * c + 7], oracle.box_decode(enc3[:, 7 * c:7 * c + 7], anchors[:100]))
+    # yaw wrap pinned to the reference's own limit_period output
+    z = np.zeros((4096, 7), np.float32)
+    z[:, 6] = g["lp_in"]
+    a1 = np.zeros((4096, 7), np.float32)
+    a1[:, 3:6] = 1
+    y = box_ops.box_decode(torch.from_numpy(z).to(dev), torch.from_numpy(a1).to(dev)).cpu().numpy()
+    assert np.array_equal(y[:, 6], g["lp_half"])
+
+
+def test_roi_align_dense_and_sparse(dev):
+    from detection_3d_amd import sparseconvnet as scn
+    from detection_3d_amd.roi_align_rotated_3d import roi_align_rotated_3d_forward, roi_align_rotated_3d_sparse
+    from tests.helpers import small_scene
+    size = (64, 64, 16)
+    _, coords, _ = small_scene(8, 9000, (1.2, 1.0, 0.3), size)
+    rng = np.random.RandomState(1)
+    C = 128
+    feats = rng.randn(coords.shape[0], C).astype(np.float32)
+    t = scn.InputLayer(3, size, mode=4)([torch.from_numpy(coords), torch.from_numpy(feats).to(dev)])
+    sop, loc = oracle.input_sites(coords)
+    f = oracle.input_forward(feats, sop, loc.shape[0], True)
+    crop = (loc[:, :3].max(0) + 1).tolist()
+    dense = oracle.sparse_to_dense(f, loc, size, 1)[:, :, :crop[0], :crop[1], :crop[2]].copy()
+    K = 60
+    rois = np.zeros((K, 8), np.float32)
+    rois[:, 1] = rng.rand(K) * crop[1] * 8
+    rois[:, 2] = rng.rand(K) * crop[0] * 8
+    rois[:, 3] = rng.rand(K) * crop[2] * 8
+    rois[:, 4] = 4 + rng.rand(K) * 200
+    rois[:, 5] = 2 + rng.rand(K) * 40
+    rois[:, 6] = 4 + rng.rand(K) * 100
+    rois[:, 7] = rng.rand(K) * 180
+    rois[:5, 1:4] += 500                                         # partly / fully outside the map
+    want = oracle.roi_align_rotated_3d(dense, rois, 1.0 / 8, 6, 8, 4, 2)
+    r = torch.from_numpy(rois).to(dev)
+    got_d = roi_align_rotated_3d_forward(torch.from_numpy(dense).to(dev), r, 1.0 / 8, 6, 8, 4, 2).cpu().numpy()
+    got_s = roi_align_rotated_3d_sparse(t, r, 1.0 / 8, 6, 8, 4, 2).cpu().numpy()
+    assert got_d.shape == (K, C, 6, 8, 4)
+    assert _close(got_d, want, 1e-5)
+    assert _close(got_s, want, 1e-5)
+    assert np.abs(want).max() > 0.1
