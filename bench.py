@@ -1,0 +1,151 @@
+"""Headline benchmark: buildings/s of full-detector inference (configs/4c fpn432, bs=1 per GPU, fp32) on
+synthetic SYNBIM-shaped scenes (500 k points), N GPUs of one node, one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one building through the whole hot path with the point cloud already resident in HBM:
+voxelize -> voxel hash-scatter -> rulebooks -> sparse FPN -> RPN -> rotated NMS -> rotated 3-D RoIAlign ->
+box head -> per-class rotated NMS.  Buildings are independent: rank r processes scenes r, r+N, ...
+(weak scaling, no data-path collective); value = buildings of all ranks / max-over-ranks time.
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP events on the launch stream inside
+the timed region) and, at N=1, `cpu_baseline` (the CPU oracle port on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=500_000)
+    ap.add_argument("--scenes", type=int, default=4, help="distinct synthetic scenes cycled per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-points", type=int, default=60_000)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, state_dict, n_points):
+    """The CPU oracle port (oracle/detector_port.py) timed on this host's cores on a bounded sample:
+    one scene of `n_points` points over the same 25 x 19 x 2.7 m footprint (same number of pyramid
+    levels and head work as the 500 k-point workload, fewer active voxels)."""
+    import oracle
+    from oracle.detector_port import OracleDetector
+    from detection_3d_amd.synthetic import make_scene
+    pcl = make_scene(1000, n_points)
+    sd = {k: v.detach().cpu() for k, v in state_dict.items()}
+    t0 = time.time()
+    coords, feats = oracle.voxelize(pcl, cfg.SPARSE3D.VOXEL_SCALE, cfg.SPARSE3D.VOXEL_FULL_SCALE)
+    det = OracleDetector(sd, cfg)
+    det(coords, feats)
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "buildings/s", "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)),
+            "kind": "port",
+            "sample": f"1 synthetic building of {n_points} points ({coords.shape[0]} kept), full detector, "
+                      f"{dt:.1f} s wall; the GPU workload has 500000 points per building"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from detection_3d_amd import _lib
+    _lib.lib()   # fail loudly without the HIP library
+    from detection_3d_amd.config import get_cfg
+    from detection_3d_amd.detector import build_detection_model
+    from detection_3d_amd.sparseconvnet import SCN
+    from detection_3d_amd.synthetic import make_scene
+    from detection_3d_amd.voxelize import voxelize
+
+    cfg = get_cfg("4c_Fpn432")
+    torch.manual_seed(0)
+    model = build_detection_model(cfg).to(dev).eval()
+    # rank r owns scenes r, r + world, ... (seeds); resident in HBM before the timed region
+    scenes = [torch.from_numpy(make_scene(rank + world * i, args.points)).to(dev) for i in range(args.scenes)]
+
+    def step(i):
+        pcl = scenes[i % len(scenes)]
+        coords, feats = voxelize(pcl, cfg.SPARSE3D.VOXEL_SCALE, cfg.SPARSE3D.VOXEL_FULL_SCALE)
+        return model([coords, feats])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    n_det = 0
+    for i in range(args.warmup):
+        n_det = step(i)["bbox3d"].shape[0]
+    prof = SCN.ConvProfiler()
+    SCN.set_profiler(prof)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    SCN.set_profiler(None)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+
+    if rank == 0:
+        summ = prof.summary()
+        # dominant sparse-conv kernel family = (kind, filter volume, Cin, Cout) with the largest summed time
+        key, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
+        per_launch_ms = d["ms"] / d["calls"]
+        tflops = d["flops"] / d["calls"] / (per_launch_ms * 1e-3) / 1e12
+        gbs = d["bytes"] / d["calls"] / (per_launch_ms * 1e-3) / 1e9
+        conv_ms = sum(v["ms"] for v in summ.values()) / args.steps
+        roof = {"bound": "mfma", "achieved": round(tflops, 3), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tflops / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+                "kernel": f"k_conv {key[0]} fv={key[1]} Cin={key[2]} Cout={key[3]}",
+                "launches_per_step": d["calls"] / args.steps, "avg_launch_us": round(per_launch_ms * 1e3, 1),
+                "algorithmic_gflop_per_launch": round(d["flops"] / d["calls"] / 1e9, 3),
+                "compulsory_GBps": round(gbs, 1), "compulsory_frac_of_hbm": round(gbs / HBM_PEAK_GBS, 4),
+                "all_sparse_conv_ms_per_step": round(conv_ms, 3)}
+        out = {
+            "metric": "buildings/sec inference, 4c_fpn432", "value": round(world * args.steps / dt_max, 3),
+            "unit": "buildings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs/4c fpn432 bs=1 fp32 full-detector inference, synthetic SYNBIM-shaped "
+                                   f"scene of {args.points} points (25x19x2.7 m), random-init weights",
+                       "points_per_building": args.points, "buildings_per_step_per_gpu": 1,
+                       "detections_last_warmup": int(n_det), "sharding": "one building per GPU, no collective"},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, model.state_dict(), args.cpu_baseline_points)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

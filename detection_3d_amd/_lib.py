@@ -32,6 +32,8 @@ _SIGS = {
     "d3d_subm_prepare": (ctypes.c_int, [vp, c_int_p, c_int_p, vp, ctypes.POINTER(ctypes.c_long)]),
     "d3d_conv_prepare": (ctypes.c_int, [vp, c_int_p, c_int_p, c_int_p, c_int_p, vp, c_int_p,
                                         ctypes.POINTER(ctypes.c_long)]),
+    "d3d_deconv_prepare": (ctypes.c_int, [vp, c_int_p, c_int_p, c_int_p, c_int_p, vp,
+                                          ctypes.POINTER(ctypes.c_long)]),
     "d3d_export_rules": (ctypes.c_int, [vp, ctypes.c_int, c_int_p, c_int_p, c_int_p, vp, ctypes.c_long,
                                         ctypes.POINTER(ctypes.c_long), vp]),
     "d3d_packed_weight_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),

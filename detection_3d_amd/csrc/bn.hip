@@ -41,15 +41,27 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x,
 
 // mode 0: batch_stats -> mean, unbiased var (torch .mean(0)/.var(0), batchNormalization.py:54-55)
 // mode 1: train       -> save_mean, save_invstd, running update (BatchNormalization.cpp:20-38)
-__global__ void k_bn_finish(const double *__restrict__ partial, int nblk, int rows, int C, int mode,
-                            float *o0, float *o1, float *running_mean, float *running_var, float eps,
-                            float momentum) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void k_bn_finish(const double *__restrict__ partial, int nblk,
+                                                   int rows, int C, int mode, float *o0, float *o1,
+                                                   float *running_mean, float *running_var,
+                                                   float eps, float momentum) {
+  // block = 32 channels x 8 slices of the partial rows; fixed summation order (deterministic)
+  __shared__ double red[256][2];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   double s = 0, ss = 0;
-  for (int b = 0; b < nblk; b++) {
-    s += partial[(size_t)b * 2 * C + c];
-    ss += partial[(size_t)b * 2 * C + C + c];
+  if (c < C)
+    for (int b = sl; b < nblk; b += 8) {
+      s += partial[(size_t)b * 2 * C + c];
+      ss += partial[(size_t)b * 2 * C + C + c];
+    }
+  red[threadIdx.x][0] = s;
+  red[threadIdx.x][1] = ss;
+  __syncthreads();
+  if (sl != 0 || c >= C) return;
+  for (int j = 1; j < 8; j++) {
+    s += red[j * 32 + cl][0];
+    ss += red[j * 32 + cl][1];
   }
   double mean = s / rows;
   double m2 = ss - mean * mean * rows;  // sum of squared deviations
@@ -122,7 +134,7 @@ static int run_partial(const float *in, int rows, int C, void *scratch, size_t s
   D3D_REQUIRE(C >= 256 ? (C % 256 == 0) : (256 % C == 0), "batch norm: planes=%d must divide 256 or be a multiple of 256", C);
   D3D_REQUIRE(scratch && scratch_bytes >= d3d_bn_scratch_bytes(C), "batch norm: scratch too small");
   int nblk = kStatBlocks;
-  if (rows < nblk * 8) nblk = (rows + 7) / 8;
+  if (rows < nblk * 64) nblk = (rows + 63) / 64;
   if (nblk < 1) nblk = 1;
   hipLaunchKernelGGL(k_bn_partial, dim3(nblk), dim3(256), 256 * 2 * sizeof(double), s, in, rows, C, (double *)scratch);
   D3D_LAUNCH_CHECK();
@@ -145,7 +157,7 @@ int d3d_bn_batch_stats(const float *in, int rows, int planes, float *mean, float
   int nblk;
   int rc = run_partial(in, rows, planes, scratch, scratch_bytes, s, &nblk);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_bn_finish, dim3((planes + 63) / 64), dim3(64), 0, s, (const double *)scratch, nblk, rows, planes, 0, mean, var_unbiased, nullptr, nullptr, 0.f, 0.f);
+  hipLaunchKernelGGL(k_bn_finish, dim3((planes + 31) / 32), dim3(256), 0, s, (const double *)scratch, nblk, rows, planes, 0, mean, var_unbiased, nullptr, nullptr, 0.f, 0.f);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }
@@ -162,7 +174,7 @@ int d3d_bn_forward(const float *in, float *out, int rows, int planes, float *sav
     int nblk;
     int rc = run_partial(in, rows, planes, scratch, scratch_bytes, s, &nblk);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_bn_finish, dim3((planes + 63) / 64), dim3(64), 0, s, (const double *)scratch, nblk, rows, planes, 1, save_mean, save_invstd, running_mean, running_var, eps, momentum);
+    hipLaunchKernelGGL(k_bn_finish, dim3((planes + 31) / 32), dim3(256), 0, s, (const double *)scratch, nblk, rows, planes, 1, save_mean, save_invstd, running_mean, running_var, eps, momentum);
   } else {
     hipLaunchKernelGGL(k_bn_eval_stats, dim3((planes + 63) / 64), dim3(64), 0, s, running_mean, running_var, planes, eps, save_mean, save_invstd);
   }

@@ -1,13 +1,14 @@
 // a6. Sparse convolution forward as ONE output-stationary launch per layer (the reference issues
 // one kernel + one blocking rule memcpy per filter offset, SCN/CUDA/RuleBookIterator.h:15-32).
 //
-// Work decomposition: a wave owns a block of 32 output rows (rows sorted by neighbour mask, see
-// grid.hip finalize_plan) and ALL Cout columns.  For every filter offset k present in the
-// block's mask it gathers the 32 input rows into its private LDS tile (full rows, 16 B per lane,
-// coalesced), then runs v_mfma_f32_32x32x2_f32 over Cin with the B operand (packed weights,
-// L2-resident) read straight from global memory.  Accumulators stay in registers across all
-// offsets; every output row is written exactly once (no atomics, deterministic).
-// Waves never synchronise with each other (no s_barrier).
+// Work decomposition: a block of 32 output rows (rows sorted by neighbour mask, see grid.hip
+// finalize_plan) is owned by COUT/32/NT waves, each holding NT 32x32 accumulator tiles.  For
+// every filter offset k present in the block's mask the waves gather the 32 input rows into an
+// LDS tile (full rows, 16 B per thread, coalesced; register-staged one step ahead so that the
+// loads overlap the matrix work), then run v_mfma_f32_32x32x2_f32 over Cin with the B operand
+// (k-interleaved packed weights, L2-resident) read straight from global memory.  Accumulators
+// stay in registers across all offsets; every output row is written exactly once (no atomics,
+// deterministic, independent of how rows are grouped).
 #include "d3d_internal.h"
 
 namespace d3d {
@@ -48,26 +49,40 @@ __global__ void k_pack_weight(const float *__restrict__ w, int fv, int cin, int 
   packed[t] = ci < cin ? w[((size_t)k * cin + ci) * cout + co] : 0.f;
 }
 
-template <int CT, int NCT, int COUT, int WPB>
-__global__ __launch_bounds__(WPB * 64) void k_conv(
+// CT   = Cin tile staged in LDS per step (multiple of 8, <= 128); NCT tiles cover Cin
+// NT   = 32-column accumulator tiles per wave; a row block is shared by WPBLK = COUT/32/NT waves
+// BPW  = row blocks per workgroup (only with WPBLK == 1, where waves never synchronise)
+template <int CT, int NCT, int COUT, int NT, int BPW>
+__global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
     const float *__restrict__ in, int cin, const float *__restrict__ wp,
     const int32_t *__restrict__ nbrT, int npos, const int32_t *__restrict__ rows,
     const uint32_t *__restrict__ blkmask, int n_blk, const float *__restrict__ residual,
     float *__restrict__ out) {
-  constexpr int LDA = CT + 4;  // +4 dwords: conflict-free ds_read_b128 of 32 rows
-  constexpr int NT = COUT / 32;
+  constexpr int WPBLK = COUT / 32 / NT;
+  static_assert(WPBLK == 1 || BPW == 1, "row blocks sharing a workgroup must be single-wave");
+  constexpr int TPB = WPBLK * 64;  // threads working on one row block
+  constexpr int LDA = CT + 4;      // +4 dwords: conflict-free ds_read_b128 of 32 rows
   constexpr int CP = CT * NCT;
-  constexpr int LPR = CT / 4;    // lanes per gathered row (16 B each)
-  constexpr int RPI = 64 / LPR;  // rows per wave-wide load instruction
-  constexpr int NIT = 32 / RPI;
-  __shared__ __attribute__((aligned(16))) float smem[WPB * 32 * LDA];
+  constexpr int LPR = CT / 4;      // threads per gathered row (16 B each)
+  constexpr int RPP = TPB / LPR;   // rows per gather pass
+  constexpr int NIT = (32 / RPP) > 0 ? (32 / RPP) : 1;
+  __shared__ __attribute__((aligned(16))) float smem[BPW * 32 * LDA];
 
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int blk = blockIdx.x * WPB + wave;
-  if (blk >= n_blk) return;  // waves are independent: no barrier below
-  float *As = smem + wave * 32 * LDA;
+  const int slot = threadIdx.x / TPB, tib = threadIdx.x % TPB;
+  const int blk = blockIdx.x * BPW + slot;
+  if (blk >= n_blk) return;  // BPW > 1 only when waves are independent (no barrier below)
+  float *As = smem + slot * 32 * LDA;
+  const int lane = tib & 63, wib = tib >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int grow = lane / LPR, gc4 = lane % LPR;
+  const int grow = tib / LPR, gc4 = tib % LPR;
+  const int colbase = wib * NT * 32;
+
+  auto block_sync = [&]() {
+    if constexpr (WPBLK == 1)
+      wave_lds_sync();
+    else
+      __syncthreads();
+  };
 
   uint32_t mask = blkmask[blk];
   const int rowid = rows[blk * 32 + r];
@@ -78,61 +93,74 @@ __global__ __launch_bounds__(WPB * 64) void k_conv(
     for (int i = 0; i < 16; i++) acc[nt][i] = 0.f;
 
   const bool vec = (cin == CP);
-  while (mask) {
-    const int k = __builtin_ctz(mask);
-    mask &= mask - 1;
-    const int src = nbrT[(size_t)k * npos + blk * 32 + r];
-#pragma unroll 1
-    for (int ct = 0; ct < NCT; ct++) {
-      // ---- gather 32 input rows (this Cin tile) into the wave's LDS tile ----
-      if (vec) {
-        f32x4 v[NIT];
+  const int32_t *nb = nbrT + blk * 32;
+  // register-staged gather of (offset k, Cin tile ct): issued one step ahead of its use
+  f32x4 stage[NIT];
+  auto issue_gather = [&](int k, int ct) {
 #pragma unroll
-        for (int it = 0; it < NIT; it++) {
-          const int s = __shfl(src, it * RPI + grow, 64);
-          f32x4 z = {0.f, 0.f, 0.f, 0.f};
-          v[it] = z;
-          if (s >= 0) v[it] = *(const f32x4 *)(in + (size_t)s * cin + ct * CT + gc4 * 4);
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; it++)
-          *(f32x4 *)(As + (it * RPI + grow) * LDA + gc4 * 4) = v[it];
-      } else {
-#pragma unroll
-        for (int it = 0; it < NIT; it++) {
-          const int s = __shfl(src, it * RPI + grow, 64);
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (s >= 0) {
-            const float *p = in + (size_t)s * cin;
+    for (int it = 0; it < NIT; it++) {
+      const int row = it * RPP + grow;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < 32) {
+        const int s = nb[(size_t)k * npos + row];
+        if (s >= 0) {
+          const float *p = in + (size_t)s * cin + ct * CT + gc4 * 4;
+          if (vec) {
+            v = *(const f32x4 *)p;
+          } else {
             const int c = ct * CT + gc4 * 4;
-            if (c + 0 < cin) v[0] = p[c + 0];
-            if (c + 1 < cin) v[1] = p[c + 1];
-            if (c + 2 < cin) v[2] = p[c + 2];
-            if (c + 3 < cin) v[3] = p[c + 3];
+            if (c + 0 < cin) v[0] = p[0];
+            if (c + 1 < cin) v[1] = p[1];
+            if (c + 2 < cin) v[2] = p[2];
+            if (c + 3 < cin) v[3] = p[3];
           }
-          *(f32x4 *)(As + (it * RPI + grow) * LDA + gc4 * 4) = v;
         }
       }
-      wave_lds_sync();
-      // ---- 32 x COUT += A[32 x CT] * W[k][CT x COUT] on the matrix cores ----
-      const float *wk = wp + ((size_t)(k * (CP / 4) + ct * (CT / 4)) * COUT) * 4;
-#pragma unroll 2
-      for (int q = 0; q < CT / 8; q++) {
-        const f32x4 a = *(const f32x4 *)(As + r * LDA + q * 8 + h * 4);
-        f32x4 b[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++)
-          b[nt] = *(const f32x4 *)(wk + ((size_t)(2 * q + h) * COUT + nt * 32 + r) * 4);
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) {
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[nt][0], acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[nt][1], acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[nt][2], acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[nt][3], acc[nt], 0, 0, 0);
-        }
-      }
-      wave_lds_sync();
+      stage[it] = v;
     }
+  };
+  auto commit_gather = [&]() {
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int row = it * RPP + grow;
+      if (row < 32) *(f32x4 *)(As + row * LDA + gc4 * 4) = stage[it];
+    }
+  };
+
+  int k = mask ? __builtin_ctz(mask) : -1;
+  int ct = 0;
+  if (k >= 0) issue_gather(k, 0);
+  while (k >= 0) {
+    commit_gather();
+    block_sync();
+    // next (offset, tile) step
+    int nk = k, nct = ct + 1;
+    if (nct == NCT) {
+      nct = 0;
+      mask &= mask - 1;
+      nk = mask ? __builtin_ctz(mask) : -1;
+    }
+    if (nk >= 0) issue_gather(nk, nct);  // loads fly while the matrix cores work
+    // ---- 32 x (NT*32) += A[32 x CT] * W[k][CT x cols] ----
+    const float *wk = wp + ((size_t)(k * (CP / 4) + ct * (CT / 4)) * COUT + colbase) * 4;
+#pragma unroll
+    for (int q = 0; q < CT / 8; q++) {
+      const f32x4 a = *(const f32x4 *)(As + r * LDA + q * 8 + h * 4);
+      f32x4 b[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++)
+        b[nt] = *(const f32x4 *)(wk + ((size_t)(2 * q + h) * COUT + nt * 32 + r) * 4);
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) {
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[nt][0], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[nt][1], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[nt][2], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[nt][3], acc[nt], 0, 0, 0);
+      }
+    }
+    block_sync();
+    k = nk;
+    ct = nct;
   }
   // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
 #pragma unroll
@@ -142,7 +170,7 @@ __global__ __launch_bounds__(WPB * 64) void k_conv(
     if (orow < 0) continue;
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
-      const size_t o = (size_t)orow * COUT + nt * 32 + r;
+      const size_t o = (size_t)orow * COUT + colbase + nt * 32 + r;
       float v = acc[nt][reg];
       if (residual) v += residual[o];
       out[o] = v;
@@ -150,24 +178,25 @@ __global__ __launch_bounds__(WPB * 64) void k_conv(
   }
 }
 
-template <int CT, int NCT, int COUT, int WPB>
+template <int CT, int NCT, int COUT, int NT, int BPW>
 static int launch_t(const Plan &p, const float *in, int cin, const float *wp, const float *residual,
                     float *out, hipStream_t s) {
-  dim3 grid((p.n_blk + WPB - 1) / WPB);
-  hipLaunchKernelGGL((k_conv<CT, NCT, COUT, WPB>), grid, dim3(WPB * 64), 0, s, in, cin, wp, p.nbrT,
+  constexpr int threads = BPW * (COUT / 32 / NT) * 64;
+  dim3 grid((p.n_blk + BPW - 1) / BPW);
+  hipLaunchKernelGGL((k_conv<CT, NCT, COUT, NT, BPW>), grid, dim3(threads), 0, s, in, cin, wp, p.nbrT,
                      p.n_blk * 32, p.rows, p.blkmask, p.n_blk, residual, out);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }
 
-template <int CT, int NCT, int WPB>
+template <int CT, int NCT>
 static int launch_c(const Plan &p, const float *in, int cin, const float *wp, int cout,
                     const float *residual, float *out, hipStream_t s) {
   switch (cout) {
-    case 32: return launch_t<CT, NCT, 32, WPB>(p, in, cin, wp, residual, out, s);
-    case 64: return launch_t<CT, NCT, 64, WPB>(p, in, cin, wp, residual, out, s);
-    case 128: return launch_t<CT, NCT, 128, WPB>(p, in, cin, wp, residual, out, s);
-    case 256: return launch_t<CT, NCT, 256, WPB>(p, in, cin, wp, residual, out, s);
+    case 32: return launch_t<CT, NCT, 32, 1, 4>(p, in, cin, wp, residual, out, s);    // 4 independent waves
+    case 64: return launch_t<CT, NCT, 64, 1, 1>(p, in, cin, wp, residual, out, s);    // 2 waves / block
+    case 128: return launch_t<CT, NCT, 128, 1, 1>(p, in, cin, wp, residual, out, s);  // 4 waves / block
+    case 256: return launch_t<CT, NCT, 256, 1, 1>(p, in, cin, wp, residual, out, s);  // 8 waves / block
   }
   set_error("convolution: Cout=%d not supported (32, 64, 128, 256)", cout);
   return D3D_ERR_UNSUPPORTED;
@@ -178,11 +207,11 @@ int launch_conv(const Plan &p, const float *in, int cin, const float *packed_w, 
   if (p.n_rows == 0) return D3D_OK;
   D3D_REQUIRE(in && packed_w && out, "convolution: null pointer");
   switch (padded_cin(cin)) {
-    case 16: return launch_c<16, 1, 4>(p, in, cin, packed_w, cout, residual, out, s);
-    case 32: return launch_c<32, 1, 4>(p, in, cin, packed_w, cout, residual, out, s);
-    case 64: return launch_c<64, 1, 4>(p, in, cin, packed_w, cout, residual, out, s);
-    case 128: return launch_c<128, 1, 2>(p, in, cin, packed_w, cout, residual, out, s);
-    case 256: return launch_c<128, 2, 2>(p, in, cin, packed_w, cout, residual, out, s);
+    case 16: return launch_c<16, 1>(p, in, cin, packed_w, cout, residual, out, s);
+    case 32: return launch_c<32, 1>(p, in, cin, packed_w, cout, residual, out, s);
+    case 64: return launch_c<64, 1>(p, in, cin, packed_w, cout, residual, out, s);
+    case 128: return launch_c<128, 1>(p, in, cin, packed_w, cout, residual, out, s);
+    case 256: return launch_c<128, 2>(p, in, cin, packed_w, cout, residual, out, s);
   }
   set_error("convolution: Cin=%d not supported (<= 256)", cin);
   return D3D_ERR_UNSUPPORTED;

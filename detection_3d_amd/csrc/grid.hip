@@ -1,6 +1,7 @@
 // Sparse-grid metadata on the device: voxel hash-scatter (input layer), strided-conv output
 // grids, submanifold / strided rulebooks ("plans"), spatial locations, sparse->dense.
 // Replaces the single-threaded CPU rule builders of SCN/Metadata/* (see include/d3d_hip.h).
+#include <algorithm>
 #include <climits>
 #include <cstring>
 
@@ -434,22 +435,27 @@ __global__ void k_export_input(const int32_t *a, int32_t *b, int n) {
 }
 
 // a1 -------------------------------------------------------------------------------------
-__global__ void k_vox_min(const float *__restrict__ pcl, int n, int nfeat, double scale,
-                          unsigned long long *mins /*3, ordered-uint encoded*/) {
-  // per-axis min of (double)x*scale; doubles mapped to order-preserving uint64 for atomicMin
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_vox_min(const float *__restrict__ pcl, int n, int nfeat,
+                                                 double scale,
+                                                 unsigned long long *mins /*3, ordered-uint*/) {
+  // per-axis min of (double)x*scale: grid-stride, wave shuffle, LDS, then ONE atomic per block
+  // (doubles mapped to order-preserving uint64)
+  __shared__ double red[4][3];
   double v[3] = {1e300, 1e300, 1e300};
-  if (i < n)
-    for (int d = 0; d < 3; d++) v[d] = (double)pcl[(size_t)i * nfeat + d] * scale;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    for (int d = 0; d < 3; d++) v[d] = fmin(v[d], (double)pcl[(size_t)i * nfeat + d] * scale);
   for (int d = 0; d < 3; d++) {
     double x = v[d];
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) x = fmin(x, __shfl_xor(x, s, 64));
-    if ((threadIdx.x & 63) == 0) {
-      unsigned long long u = (unsigned long long)__double_as_longlong(x);
-      u = (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-      atomicMin(&mins[d], u);
-    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][d] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double x = fmin(fmin(red[0][threadIdx.x], red[1][threadIdx.x]), fmin(red[2][threadIdx.x], red[3][threadIdx.x]));
+    unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    u = (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+    atomicMin(&mins[threadIdx.x], u);
   }
 }
 __device__ __forceinline__ double decode_ordered(unsigned long long u) {
@@ -552,7 +558,7 @@ int d3d_voxelize(const float *pcl, int n, int nfeat, double scale, const int *fu
   D3D_ALLOC(flag, int32_t, A, n);
   D3D_ALLOC(rank, int32_t, A, n);
   D3D_HIP_CHECK(hipMemsetAsync(mins, 0xFF, 4 * sizeof(unsigned long long), s));
-  hipLaunchKernelGGL(k_vox_min, grid1d(n), dim3(256), 0, s, pcl, n, nfeat, scale, mins);
+  hipLaunchKernelGGL(k_vox_min, dim3(std::min(1024u, grid1d(n).x)), dim3(256), 0, s, pcl, n, nfeat, scale, mins);
   hipLaunchKernelGGL(k_vox_flag, grid1d(n), dim3(256), 0, s, pcl, n, nfeat, scale, mins, full[0], full[1], full[2], flag);
   int rc = scan_exclusive_i32(flag, rank, n, (int32_t *)(mins + 3), A, s);
   if (rc) return rc;
@@ -758,7 +764,7 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
       geo.stride[d] = stride[d];
       geo.out_size[d] = out_size[d];
       K *= filt[d];
-      max_out *= (filt[d] + stride[d] - 1) / stride[d];
+      max_out *= std::min((filt[d] + stride[d] - 1) / stride[d], out_size[d]);
     }
     geo.max_out = max_out;
     D3D_REQUIRE(K <= 32, "filter volume %d not supported (<= 32)", K);
@@ -831,6 +837,17 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
   }
   if (n_out_host) *n_out_host = it->second.n_rows;
   if (n_rules_host) *n_rules_host = it->second.n_rules;
+  return D3D_OK;
+}
+
+int d3d_deconv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const int *filt,
+                       const int *stride, void *stream, long *n_rules_host) {
+  (void)in_size;
+  D3D_REQUIRE(m && out_size && filt && stride, "null argument");
+  const Plan *p = nullptr;
+  int rc = get_deconv_plan(m, out_size, filt, stride, (hipStream_t)stream, &p);
+  if (rc) return rc;
+  if (n_rules_host) *n_rules_host = p->n_rules;
   return D3D_OK;
 }
 

@@ -1,0 +1,314 @@
+"""Inference path of the reference's SparseRCNN (maskrcnn_benchmark/modeling/detector/sparse_rcnn.py:37-76)
+for the non-separated configs (4c / 6c): backbone -> RPN head -> anchors -> top-k + decode + rotated NMS
+-> rotated 3-D RoIAlign -> box head -> per-class rotated NMS -> top detections.
+
+Module / parameter names follow the reference so that its checkpoints load unchanged
+(`backbone.*`, `rpn.head.{conv,cls_logits,bbox_pred}.*`,
+`roi_heads.box.feature_extractor.{conv3d.0,conv3d.1,fc6,fc7}.*`, `roi_heads.box.predictor.*`).
+Dense per-site / per-RoI linear algebra (1x1 convs, fc layers) runs on rocBLAS / MIOpen through
+PyTorch; everything sparse, geometric or combinatorial runs in libd3d_hip.so.
+
+Boxes are plain tensors [n,7] in yx_zb mode (xc, yc, z_bot, dy, dx, dz, yaw) instead of BoxList3D
+objects; fields travel next to them in a small dict.  SEPARATE_CLASSES (3G6c) is not wired yet.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import box_ops
+from . import sparseconvnet as scn
+from .config import class_to_label
+from .roi_align_rotated_3d import roi_align_rotated_3d_sparse
+
+
+def build_backbone(cfg):
+    """maskrcnn_benchmark/modeling/backbone/backbone.py:38-69 ("Sparse-R-50-FPN")."""
+    s = cfg.SPARSE3D
+    return scn.FPN_Net(s.VOXEL_FULL_SCALE, 3, cfg.INPUT.ELEMENTS, s.BLOCK_REPS, s.nPlanesFront,
+                       nPlaneM=s.nPlaneMap, residual_blocks=s.RESIDUAL_BLOCK,
+                       fpn_scales_from_top=cfg.MODEL.RPN.RPN_SCALES_FROM_TOP,
+                       roi_scales_from_top=cfg.MODEL.ROI_BOX_HEAD.POOLER_SCALES_FROM_TOP,
+                       downsample=[s.KERNEL, s.STRIDE], rpn_map_sizes=cfg.MODEL.RPN.RPN_MAP_SIZES,
+                       voxel_scale=s.VOXEL_SCALE, rpn_3d_2d_selector=cfg.MODEL.RPN.RPN_3D_2D_SELECTOR,
+                       bn_momentum=cfg.SOLVER.BN_MOMENTUM, track_running_stats=cfg.SOLVER.TRACK_RUNNING_STATS)
+
+
+# ----------------------------------------------------------------------------------------------
+class AnchorGenerator(nn.Module):
+    """modeling/rpn/anchor_generator_sparse3d.py:44-120,207-241: one anchor size per selected map,
+    4 anchors per active site (4 yaws, or 4 size ratios with yaw 0)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        rpn = cfg.MODEL.RPN
+        yaws = np.array(rpn.YAWS, dtype=np.float32).reshape(-1, 1)
+        ratios = np.array(rpn.RATIOS, dtype=np.float32)
+        cells = []
+        for size, use_yaw in zip(np.array(rpn.ANCHOR_SIZES_3D, dtype=np.float32), rpn.USE_YAWS):
+            rows = []
+            for j in range(yaws.shape[0]):
+                if use_yaw:
+                    rows.append(np.concatenate([np.zeros(3, np.float32), size, yaws[j]]))
+                else:
+                    rows.append(np.concatenate([np.zeros(3, np.float32), size * ratios[j], np.zeros(1, np.float32)]))
+            cells.append(torch.from_numpy(np.stack(rows).astype(np.float32)))
+        self.cell_anchors = cells
+        self.strides = torch.tensor(np.array(rpn.ANCHOR_STRIDE, dtype=np.float32))
+        self.voxel_scale = cfg.SPARSE3D.VOXEL_SCALE
+        self.anchor_num_per_loc = yaws.shape[0]
+
+    def num_anchors_per_location(self):
+        return self.anchor_num_per_loc
+
+    def forward(self, feature_maps_sparse):
+        anchors = []
+        for base, fmap, stride in zip(self.cell_anchors, feature_maps_sparse, self.strides):
+            loc = fmap.get_spatial_locations()
+            dev = loc.device
+            cent = loc[:, 0:3].float() / self.voxel_scale * stride.to(dev).view(1, 3)     # :99
+            cent = torch.cat([cent, torch.zeros(cent.shape[0], 4, device=dev)], 1).view(-1, 1, 7)
+            anchors.append((cent + base.to(dev).view(1, -1, 7)).reshape(-1, 7))
+        return anchors
+
+
+class RPNHead(nn.Module):
+    """modeling/rpn/rpn_sparse3d.py:80-131 (SingleConvRPNHead_Sparse3D): three 1x1 convolutions over
+    the active sites, i.e. per-site linear layers.  Parameters keep the Conv2d shapes [out,in,1,1]."""
+
+    def __init__(self, cfg, in_channels, num_anchors_per_location):
+        super().__init__()
+        self.num_anchors_per_location = num_anchors_per_location
+        self.seperate_rpn = int(len(cfg.MODEL.SEPARATE_CLASSES) * cfg.MODEL.SEPARATE_RPN) + 1
+        a = num_anchors_per_location * self.seperate_rpn
+        self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=1)
+        self.cls_logits = nn.Conv2d(in_channels, a, kernel_size=1)
+        self.bbox_pred = nn.Conv2d(in_channels, a * 7, kernel_size=1)
+        for l in (self.conv, self.cls_logits, self.bbox_pred):
+            nn.init.normal_(l.weight, std=0.01)
+            nn.init.constant_(l.bias, 0)
+
+    @staticmethod
+    def _lin(layer, x):
+        return F.linear(x, layer.weight.view(layer.weight.shape[0], -1), layer.bias)
+
+    def forward(self, features):
+        """features: list of [n_s, C]  ->  objectness [sum n_s*A], regression [sum n_s*A, 7] in the
+        flattening order of cat_scales_obj_reg (:19-77): scale, site, anchor."""
+        obj, reg = [], []
+        for f in features:
+            t = F.relu(self._lin(self.conv, f))
+            obj.append(self._lin(self.cls_logits, t).reshape(-1, self.seperate_rpn))
+            reg.append(self._lin(self.bbox_pred, t).reshape(-1, 7 * self.seperate_rpn))
+        return torch.cat(obj, 0), torch.cat(reg, 0)
+
+
+class RPNModule(nn.Module):
+    """modeling/rpn/rpn_sparse3d.py:137-231 + rpn/inference_3d.py:82-163 (test path)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.anchor_generator = AnchorGenerator(cfg)
+        self.head = RPNHead(cfg, cfg.MODEL.BACKBONE.OUT_CHANNELS, self.anchor_generator.num_anchors_per_location())
+        rpn = cfg.MODEL.RPN
+        self.pre_nms_top_n = rpn.FPN_PRE_NMS_TOP_N_TEST
+        self.post_nms_top_n = rpn.FPN_POST_NMS_TOP_N_TEST
+        self.nms_thresh = rpn.NMS_THRESH
+        self.nms_aug_thickness = list(rpn.NMS_AUG_THICKNESS_Y_Z)
+
+    @torch.no_grad()
+    def forward(self, features_sparse):
+        objectness, box_regression = self.head([f.features for f in features_sparse])
+        anchors = torch.cat(self.anchor_generator(features_sparse), 0)
+        assert objectness.shape[0] == box_regression.shape[0] == anchors.shape[0]
+        scores = objectness.reshape(-1).sigmoid()
+        k = min(self.pre_nms_top_n, scores.shape[0])
+        scores_k, idx = scores.topk(k, dim=0, sorted=True)                      # inference_3d.py:109
+        proposals = box_ops.box_decode(box_regression[idx], anchors[idx])       # :123
+        keep = box_ops.nms_3d_clamped(proposals, scores_k, self.nms_thresh, self.nms_aug_thickness,
+                                      max_proposals=self.post_nms_top_n, flag='rpn_post')
+        return proposals[keep], scores_k[keep]
+
+
+# ----------------------------------------------------------------------------------------------
+def convert_to_roi_format(boxes_yxzb):
+    """modeling/poolers_3d.py:107-124 with BoxList3D.convert('standard')
+    (structures/bounding_box_3d.py:221-242, limit_yaw in the constructor :167): batch id 0."""
+    b = boxes_yxzb
+    std = b[:, [0, 1, 2, 4, 3, 5, 6]].clone()
+    std[:, 2] += b[:, 5] * 0.5
+    std[:, 6] += math.pi * 0.5
+    std[:, 6] = box_ops.limit_period(std[:, 6], 0.0, math.pi)
+    rois = torch.cat([torch.zeros((b.shape[0], 1), dtype=b.dtype, device=b.device), std], 1)
+    rois = rois[:, [0, 2, 1, 3, 5, 4, 6, 7]]
+    rois[:, -1] *= 180.0 / math.pi
+    return rois
+
+
+class Pooler(nn.Module):
+    """modeling/poolers_3d.py:57-69,73-168 on sparse maps (no dense intermediate)."""
+
+    def __init__(self, output_size, scales, sampling_ratio, canonical_size):
+        super().__init__()
+        self.output_size, self.scales = tuple(output_size), list(scales)
+        self.sampling_ratio, self.canonical_size = sampling_ratio, canonical_size
+
+    def map_levels(self, boxes):
+        size = torch.sqrt(boxes[:, 3:5].max(dim=1)[0])
+        rate = size / self.canonical_size
+        dif = torch.abs(torch.tensor(self.scales, device=boxes.device)[None, :] - rate[:, None])
+        return torch.argmin(dif, 1)
+
+    @torch.no_grad()
+    def forward(self, x, boxes_pixels):
+        rois = convert_to_roi_format(boxes_pixels)
+        ph, pw, pz = self.output_size
+        if len(self.scales) == 1:
+            return roi_align_rotated_3d_sparse(x[0], rois, self.scales[0], ph, pw, pz, self.sampling_ratio)
+        levels = self.map_levels(boxes_pixels)
+        result = torch.zeros((rois.shape[0], x[0].features.shape[1], ph, pw, pz), dtype=torch.float32,
+                             device=rois.device)
+        for level, (fmap, scale) in enumerate(zip(x, self.scales)):
+            idx = torch.nonzero(levels == level).squeeze(1)
+            if idx.numel():
+                result[idx] = roi_align_rotated_3d_sparse(fmap, rois[idx].contiguous(), scale, ph, pw, pz,
+                                                          self.sampling_ratio)
+        return result
+
+
+class FPN2MLPFeatureExtractor(nn.Module):
+    """roi_heads/box_head_3d/roi_box_feature_extractors.py:47-117."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        head = cfg.MODEL.ROI_BOX_HEAD
+        res = head.POOLER_RESOLUTION
+        self.pooler = Pooler(res, head.POOLER_SCALES_SPATIAL, head.POOLER_SAMPLING_RATIO, head.CANONICAL_SIZE)
+        self.voxel_scale = cfg.SPARSE3D.VOXEL_SCALE
+        c, rep = cfg.MODEL.BACKBONE.OUT_CHANNELS, head.MLP_HEAD_DIM
+        self.conv3d = nn.Sequential(nn.Conv3d(c, rep, kernel_size=[1, 1, res[2]], stride=[1, 1, 1]),
+                                    nn.BatchNorm3d(rep, track_running_stats=cfg.SOLVER.TRACK_RUNNING_STATS),
+                                    nn.ReLU(inplace=True))
+        self.fc6 = nn.Linear(c * res[0] * res[1] * res[2], rep)
+        self.fc7 = nn.Linear(rep, rep)
+        for l in (self.fc6, self.fc7):
+            nn.init.kaiming_uniform_(l.weight, a=1)
+            nn.init.constant_(l.bias, 0)
+
+    def forward(self, x0, proposals):
+        p = proposals.clone()
+        p[:, 0:6] *= self.voxel_scale                                           # convert_metric_to_pixel
+        x1 = self.conv3d(self.pooler(x0, p))
+        x2 = x1.view(x1.size(0), -1)
+        return F.relu(self.fc7(F.relu(self.fc6(x2))))
+
+
+class FPNPredictor(nn.Module):
+    """roi_heads/box_head_3d/roi_box_predictors.py:33-55."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        nc = len(cfg.INPUT.CLASSES) + len(cfg.MODEL.SEPARATE_CLASSES)
+        rep = cfg.MODEL.ROI_BOX_HEAD.MLP_HEAD_DIM
+        self.cls_score = nn.Linear(rep, nc)
+        self.bbox_pred = nn.Linear(rep, nc * 7)
+        nn.init.normal_(self.cls_score.weight, std=0.01)
+        nn.init.normal_(self.bbox_pred.weight, std=0.001)
+        for l in (self.cls_score, self.bbox_pred):
+            nn.init.constant_(l.bias, 0)
+
+    def forward(self, x):
+        return self.cls_score(x), self.bbox_pred(x)
+
+
+class PostProcessor(nn.Module):
+    """roi_heads/box_head_3d/inference.py:40-149."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        rh = cfg.MODEL.ROI_HEADS
+        self.score_thresh, self.nms = rh.SCORE_THRESH, rh.NMS
+        self.nms_aug_thickness = list(rh.NMS_AUG_THICKNESS_Y_Z)
+        self.detections_per_img = rh.DETECTIONS_PER_IMG
+        self.weights = tuple(rh.BBOX_REG_WEIGHTS)
+
+    @torch.no_grad()
+    def forward(self, class_logits, box_regression, proposals):
+        prob = F.softmax(class_logits, -1)
+        boxes = box_ops.box_decode(box_regression, proposals, self.weights)     # [K, 7*nc]
+        nc = prob.shape[1]
+        out_b, out_s, out_l = [], [], []
+        inds_all = prob > self.score_thresh
+        for j in range(1, nc):
+            inds = inds_all[:, j].nonzero().squeeze(1)
+            if inds.numel() == 0:
+                continue
+            sj = prob[inds, j]
+            bj = boxes[inds, j * 7:(j + 1) * 7].contiguous()
+            keep = box_ops.nms_3d_clamped(bj, sj, self.nms, self.nms_aug_thickness, -1, flag='roi_post')
+            out_b.append(bj[keep])
+            out_s.append(sj[keep])
+            out_l.append(torch.full((keep.numel(),), j, dtype=torch.int64, device=prob.device))
+        if not out_b:
+            z = prob.new_zeros
+            return {"bbox3d": z((0, 7)), "scores": z((0,)), "labels": torch.zeros(0, dtype=torch.int64, device=prob.device)}
+        b, s, l = torch.cat(out_b), torch.cat(out_s), torch.cat(out_l)
+        n = s.shape[0]
+        if n > self.detections_per_img > 0:                                      # :140-148
+            thresh = torch.kthvalue(s, n - self.detections_per_img + 1)[0]
+            keep = torch.nonzero(s >= thresh).squeeze(1)
+            b, s, l = b[keep], s[keep], l[keep]
+        return {"bbox3d": b, "scores": s, "labels": l}
+
+
+class ROIBoxHead3D(nn.Module):
+    """roi_heads/box_head_3d/box_head.py (test path)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.feature_extractor = FPN2MLPFeatureExtractor(cfg)
+        self.predictor = FPNPredictor(cfg)
+        self.post_processor = PostProcessor(cfg)
+
+    def forward(self, roi_features, proposals):
+        x = self.feature_extractor(roi_features, proposals)
+        logits, reg = self.predictor(x)
+        return self.post_processor(logits, reg, proposals)
+
+
+class _RoiHeads(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.box = ROIBoxHead3D(cfg)
+
+
+class SparseRCNN(nn.Module):
+    """Inference of one batch: points = [coords int64 [N,3|4], feats fp32 [N,9]]."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        if len(cfg.MODEL.SEPARATE_CLASSES):
+            raise NotImplementedError("SEPARATE_CLASSES (3G6c) grouping is a 'next' row (SURVEY.md 8f rank 4)")
+        self.cfg = cfg
+        self.backbone = build_backbone(cfg)
+        self.rpn = RPNModule(cfg)
+        self.roi_heads = _RoiHeads(cfg)
+        self.class_to_label = class_to_label(cfg.INPUT.CLASSES)
+
+    @torch.no_grad()
+    def forward(self, points, return_intermediates=False):
+        rpn_features, roi_features = self.backbone(points)
+        proposals, objectness = self.rpn(rpn_features)
+        proposals = proposals.clone()
+        proposals[:, 3:6] = torch.clamp(proposals[:, 3:6], min=0.001)           # BoxList3D.clamp_size
+        result = self.roi_heads.box(roi_features, proposals)
+        if return_intermediates:
+            return result, {"rpn_features": rpn_features, "roi_features": roi_features,
+                            "proposals": proposals, "objectness": objectness}
+        return result
+
+
+def build_detection_model(cfg):
+    return SparseRCNN(cfg)

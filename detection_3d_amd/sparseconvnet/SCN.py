@@ -28,6 +28,46 @@ def _scratch(device, nbytes):
     return buf
 
 
+class ConvProfiler(object):
+    """Optional per-launch timing of the sparse convolutions with HIP events recorded on the
+    stream the kernels are launched on (bench.py's roofline leg).  Off by default."""
+
+    def __init__(self):
+        self.records = []   # (key, flops, compulsory_bytes, start_event, end_event)
+
+    def begin(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def end(self, start, kind, fv, cin, cout, rows_in, rows_out, macs):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        rules = macs / max(cin * cout, 1)
+        # SURVEY.md 8(d): FLOPs = 2*rules*Cin*Cout; compulsory bytes = 4*(rows_in*Cin + rows_out*Cout) + 8*rules
+        self.records.append(((kind, fv, cin, cout), 2.0 * macs, 4.0 * (rows_in * cin + rows_out * cout) + 8.0 * rules,
+                             start, ev))
+
+    def summary(self):
+        """{key: dict(calls, ms, flops, bytes)}; call after torch.cuda.synchronize()."""
+        out = {}
+        for key, flops, nbytes, s, e in self.records:
+            d = out.setdefault(key, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["calls"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        return out
+
+
+PROFILER = None
+
+
+def set_profiler(p):
+    global PROFILER
+    PROFILER = p
+
+
 def _size3(t):
     v = [int(x) for x in (t.tolist() if hasattr(t, "tolist") else t)]
     assert len(v) == 3, "only dimension 3 is built (Metadata_3)"
@@ -162,9 +202,15 @@ def SubmanifoldConvolution_updateOutput(spatial_size, filter_size, m, input_feat
     n = m.getNActive(size)
     output_features.resize_(n, cout)
     macs = ctypes.c_double(0)
+    prof = PROFILER
+    if prof is not None:   # make sure the rulebook build is not inside the timed launch
+        check(lib().d3d_subm_prepare(m._h, ints(size), ints(filt), stream_of(), None))
+        t0 = prof.begin()
     check(lib().d3d_subm_conv_forward(m._h, ints(size), ints(filt), ptr(input_features), cin, ptr(packed),
                                       cout, ptr(residual), ptr(output_features), stream_of(),
                                       ctypes.byref(macs)))
+    if prof is not None:
+        prof.end(t0, "subm", fv, cin, cout, n, n, macs.value)
     return macs.value
 
 
@@ -181,8 +227,13 @@ def Convolution_updateOutput(input_size, output_size, filter_size, filter_stride
                                  ctypes.byref(n_out), None))
     output_features.resize_(n_out.value, cout)
     macs = ctypes.c_double(0)
+    prof = PROFILER
+    if prof is not None:
+        t0 = prof.begin()
     check(lib().d3d_conv_forward(m._h, ints(isz), ints(osz), ints(filt), ints(st), ptr(input_features), cin,
                                  ptr(packed), cout, ptr(output_features), stream_of(), ctypes.byref(macs)))
+    if prof is not None:
+        prof.end(t0, "conv", fv, cin, cout, input_features.shape[0], n_out.value, macs.value)
     return macs.value
 
 
@@ -197,9 +248,15 @@ def Deconvolution_updateOutput(input_size, output_size, filter_size, filter_stri
     n = m.getNActive(osz)
     output_features.resize_(n, cout)
     macs = ctypes.c_double(0)
+    prof = PROFILER
+    if prof is not None:
+        check(lib().d3d_deconv_prepare(m._h, ints(isz), ints(osz), ints(filt), ints(st), stream_of(), None))
+        t0 = prof.begin()
     check(lib().d3d_deconv_forward(m._h, ints(isz), ints(osz), ints(filt), ints(st), ptr(input_features),
                                    cin, ptr(packed), cout, ptr(residual), ptr(output_features), stream_of(),
                                    ctypes.byref(macs)))
+    if prof is not None:
+        prof.end(t0, "deconv", fv, cin, cout, input_features.shape[0], n, macs.value)
     return macs.value
 
 

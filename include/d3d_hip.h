@@ -83,6 +83,11 @@ int d3d_subm_prepare(d3d_meta *m, const int *spatial_size_host, const int *filte
 int d3d_conv_prepare(d3d_meta *m, const int *in_size_host, const int *out_size_host,
                      const int *filter_host, const int *stride_host, void *stream,
                      int *n_out_host, long *n_rules_host);
+/* Deconvolution view of the strided rulebook of (fine size `out_size`, filter, stride): rows are the
+ * fine sites (SCN/CPU/Deconvolution.cpp:17).  Requires the matching d3d_conv_prepare.          */
+int d3d_deconv_prepare(d3d_meta *m, const int *in_size_host, const int *out_size_host,
+                       const int *filter_host, const int *stride_host, void *stream,
+                       long *n_rules_host);
 /* debug exporter: rulebook as (in,out,offset) int32 triples in unspecified order; capacity in
  * triples; *n_host receives the count.  kind: 0 submanifold (out_size ignored), 1 strided.    */
 int d3d_export_rules(d3d_meta *m, int kind, const int *in_size_host, const int *filter_host,

@@ -1,0 +1,226 @@
+"""TEST INFRASTRUCTURE ONLY: CPU composition of the detector's inference path out of oracle ops
+(sparse path, boxes) and plain torch-CPU dense layers, driven by a state_dict with the reference's
+key names.  Used by tests/ as the checker and by bench.py's cpu_baseline leg ("port") only."""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import (bn_forward, box_decode, conv_rules, input_forward, input_sites, nbr_conv, roi_align_rotated_3d,
+               rotate_nms_3d, rule_conv, sparse_to_dense, subm_nbr)
+
+
+class OracleFPN:
+    """FPN_Net forward (SparseConvNet/sparseconvnet/fpn_net.py:140-203), eval mode with
+    track_running_stats=False: every BN normalises with the batch mean / unbiased variance
+    (sparseconvnet/batchNormalization.py:51-56)."""
+
+    def __init__(self, sd, full_scale, n_scales, fpn_scales_from_top, roi_scales_from_top,
+                 rpn_3d_2d_selector, eps=1e-4, leakiness=0.0, prefix=""):
+        self.sd = {k[len(prefix):]: v.detach().cpu().numpy() for k, v in sd.items() if k.startswith(prefix)}
+        self.full = np.asarray(full_scale)
+        self.n_scales = n_scales
+        self.fpn, self.roi, self.sel = list(fpn_scales_from_top), list(roi_scales_from_top), list(rpn_3d_2d_selector)
+        self.eps, self.leak = eps, leakiness
+
+    def w(self, key):
+        w = self.sd[key]
+        return w.reshape(w.shape[0], w.shape[2], w.shape[3])
+
+    def bn(self, x, prefix):
+        mean = x.mean(0, dtype=np.float64).astype(np.float32)
+        var = x.var(0, ddof=1, dtype=np.float64).astype(np.float32)
+        out, *_ = bn_forward(x, mean, var, self.sd[prefix + ".weight"], self.sd[prefix + ".bias"],
+                             self.eps, 0.0, False, self.leak)
+        return out
+
+    def subm(self, x, loc, key, filt=(3, 3, 3)):
+        ck = (id(loc), tuple(filt))
+        if ck not in self._nbr:
+            self._nbr[ck] = subm_nbr(loc, filt)[0]
+        return nbr_conv(x, self.w(key), self._nbr[ck])
+
+    def __call__(self, coords, feats):
+        self._nbr = {}
+        sop, loc0 = input_sites(coords)
+        x = input_forward(feats, sop, loc0.shape[0], True)
+        x = self.subm(x, loc0, "layers_in.1.weight")
+        locs, rules, downs = [loc0], [], []
+        for k in range(self.n_scales):
+            if k > 0:
+                pre = f"m_downs.{k}.0"
+                y = self.bn(x, pre + ".0")
+                size = self.full // (2 ** k)
+                lo, ru = conv_rules(locs[-1], [2, 2, 2], [2, 2, 2], size)
+                locs.append(lo)
+                rules.append(ru)
+                x = rule_conv(y, self.w(pre + ".1.weight"), ru, lo.shape[0])
+                blk = f"m_downs.{k}.1.1"
+            else:
+                blk = "m_downs.0.0.1"
+            y = self.bn(x, blk + ".0")
+            y = self.subm(y, locs[k], blk + ".1.weight")
+            y = self.bn(y, blk + ".2")
+            y = self.subm(y, locs[k], blk + ".3.weight")
+            x = x + y
+            downs.append(x)
+        top = self.n_scales - 1
+        net = self.subm(downs[top], locs[top], f"m_shortcuts.{top}.weight", (1, 1, 1))
+        ups = [net]
+        need = max(self.fpn + self.roi)
+        for k in range(need):
+            j = self.n_scales - 2 - k
+            y = self.bn(net, f"m_ups.{k}.0")
+            y = rule_conv(y, self.w(f"m_ups.{k}.1.weight"), rules[j], locs[j].shape[0], deconv=True)
+            sc = self.subm(downs[j], locs[j], f"m_shortcuts.{j}.weight", (1, 1, 1))
+            net = y + sc
+            ups.append(self.subm(net, locs[j], f"m_mergeds.{k}.weight"))
+        up_locs = [locs[self.n_scales - 1 - i] for i in range(len(ups))]
+        maps3d = [(ups[i], up_locs[i]) for i in self.fpn]
+        maps2d = []
+        for i, (f, lo) in enumerate(maps3d):
+            size = self.full // (2 ** (self.n_scales - 1 - self.fpn[i]))
+            z = int(size[2])
+            if (i + len(maps3d)) in self.sel:
+                lo2, ru2 = conv_rules(lo, [1, 1, z], [1, 1, 1], [size[0], size[1], 1])
+                maps2d.append((rule_conv(f, self.w(f"convs_pro2d.{i}.weight"), ru2, lo2.shape[0]), lo2))
+            else:
+                maps2d.append(None)
+        allmaps = maps3d + maps2d
+        rpn = [allmaps[i] for i in self.sel]
+        roi = [(ups[i], up_locs[i], self.full // (2 ** (self.n_scales - 1 - i))) for i in self.roi]
+        return rpn, roi
+
+
+def _lin(sd, name, x):
+    w = sd[name + ".weight"].detach().cpu().float()
+    b = sd[name + ".bias"].detach().cpu().float()
+    return F.linear(x, w.view(w.shape[0], -1), b)
+
+
+def nms_clamped(boxes, scores, thresh, aug, max_keep, pre_max=2000):
+    """boxlist_nms_3d (structures/boxlist_ops_3d.py:14-62): clamp for the IoU only, pre_max 2000."""
+    b = np.asarray(boxes, np.float32).copy()
+    b[:, 3:5] = np.maximum(b[:, 3:5], aug[0])
+    b[:, 5] = np.maximum(b[:, 5], aug[1])
+    order = np.argsort(-np.asarray(scores, np.float64), kind="stable")[:pre_max]
+    keep = rotate_nms_3d(b[order], np.asarray(scores, np.float32)[order], thresh)[:max_keep]
+    return order[keep]
+
+
+def rois_from_boxes(boxes_pixels):
+    """modeling/poolers_3d.py:107-124 (+ BoxList3D.convert('standard'))."""
+    b = torch.as_tensor(boxes_pixels, dtype=torch.float32)
+    std = b[:, [0, 1, 2, 4, 3, 5, 6]].clone()
+    std[:, 2] += b[:, 5] * 0.5
+    std[:, 6] += math.pi * 0.5
+    std[:, 6] = std[:, 6] - torch.floor(std[:, 6] / math.pi + 0.0) * math.pi
+    rois = torch.cat([torch.zeros((b.shape[0], 1)), std], 1)[:, [0, 2, 1, 3, 5, 4, 6, 7]]
+    rois[:, -1] *= 180.0 / math.pi
+    return rois.numpy()
+
+
+class OracleDetector:
+    """SparseRCNN inference (modeling/detector/sparse_rcnn.py:37-76) on the CPU."""
+
+    def __init__(self, sd, cfg):
+        self.sd, self.cfg = sd, cfg
+        s = cfg.SPARSE3D
+        self.fpn = OracleFPN(sd, s.VOXEL_FULL_SCALE, len(s.nPlanesFront), cfg.MODEL.RPN.RPN_SCALES_FROM_TOP,
+                             cfg.MODEL.ROI_BOX_HEAD.POOLER_SCALES_FROM_TOP, cfg.MODEL.RPN.RPN_3D_2D_SELECTOR,
+                             prefix="backbone.")
+
+    def anchors(self, locs):
+        rpn = self.cfg.MODEL.RPN
+        out = []
+        for size, use_yaw, stride, loc in zip(rpn.ANCHOR_SIZES_3D, rpn.USE_YAWS, rpn.ANCHOR_STRIDE, locs):
+            base = np.zeros((len(rpn.YAWS), 7), np.float32)
+            for j in range(len(rpn.YAWS)):
+                if use_yaw:
+                    base[j, 3:6], base[j, 6] = size, rpn.YAWS[j]
+                else:
+                    base[j, 3:6] = np.float32(size) * np.float32(rpn.RATIOS[j])
+            cent = loc[:, :3].astype(np.float32) / np.float32(self.cfg.SPARSE3D.VOXEL_SCALE) * np.asarray(stride, np.float32)
+            a = np.zeros((loc.shape[0], len(rpn.YAWS), 7), np.float32)
+            a[:, :, :3] = cent[:, None, :]
+            out.append((a + base[None]).reshape(-1, 7))
+        return np.concatenate(out)
+
+    def rpn(self, rpn_maps):
+        rc = self.cfg.MODEL.RPN
+        obj, reg = [], []
+        for f, _ in rpn_maps:
+            t = F.relu(_lin(self.sd, "rpn.head.conv", torch.from_numpy(f)))
+            obj.append(_lin(self.sd, "rpn.head.cls_logits", t).reshape(-1))
+            reg.append(_lin(self.sd, "rpn.head.bbox_pred", t).reshape(-1, 7))
+        scores = torch.cat(obj).sigmoid()
+        reg = torch.cat(reg)
+        anchors = self.anchors([l for _, l in rpn_maps])
+        k = min(rc.FPN_PRE_NMS_TOP_N_TEST, scores.shape[0])
+        sk, idx = scores.topk(k, sorted=True)
+        props = box_decode(reg[idx].numpy(), anchors[idx.numpy()])
+        keep = nms_clamped(props, sk.numpy(), rc.NMS_THRESH, rc.NMS_AUG_THICKNESS_Y_Z, rc.FPN_POST_NMS_TOP_N_TEST)
+        return props[keep], sk.numpy()[keep]
+
+    def pool(self, roi_maps, proposals):
+        head = self.cfg.MODEL.ROI_BOX_HEAD
+        p = np.asarray(proposals, np.float32).copy()
+        p[:, 0:6] *= self.cfg.SPARSE3D.VOXEL_SCALE
+        rois = rois_from_boxes(p)
+        size = np.sqrt(p[:, 3:5].max(1))
+        dif = np.abs(np.asarray(head.POOLER_SCALES_SPATIAL, np.float32)[None] - (size / np.float32(head.CANONICAL_SIZE))[:, None])
+        levels = dif.argmin(1)
+        ph, pw, pz = head.POOLER_RESOLUTION
+        out = np.zeros((p.shape[0], roi_maps[0][0].shape[1], ph, pw, pz), np.float32)
+        for lvl, (f, loc, size3) in enumerate(roi_maps):
+            idx = np.nonzero(levels == lvl)[0]
+            if not len(idx):
+                continue
+            crop = loc[:, :3].max(0) + 1                                  # tools_3d_2d.py:16-29
+            dense = sparse_to_dense(f, loc, [int(v) for v in crop], 1)      # same values as crop of the full map
+            out[idx] = roi_align_rotated_3d(dense, rois[idx], head.POOLER_SCALES_SPATIAL[lvl], ph, pw, pz,
+                                            head.POOLER_SAMPLING_RATIO)
+        return out
+
+    def box_head(self, pooled):
+        sd = self.sd
+        x = torch.from_numpy(pooled)
+        pre = "roi_heads.box.feature_extractor."
+        x = F.conv3d(x, sd[pre + "conv3d.0.weight"].cpu().float(), sd[pre + "conv3d.0.bias"].cpu().float())
+        x = F.relu(F.batch_norm(x, None, None, sd[pre + "conv3d.1.weight"].cpu().float(),
+                                sd[pre + "conv3d.1.bias"].cpu().float(), True, 0.1, 1e-5))
+        x = x.reshape(x.shape[0], -1)
+        x = F.relu(_lin(sd, pre + "fc6", x))
+        x = F.relu(_lin(sd, pre + "fc7", x))
+        return _lin(sd, "roi_heads.box.predictor.cls_score", x), _lin(sd, "roi_heads.box.predictor.bbox_pred", x)
+
+    def post(self, logits, reg, proposals):
+        rh = self.cfg.MODEL.ROI_HEADS
+        prob = F.softmax(logits, -1).numpy()
+        nc = prob.shape[1]
+        reg = reg.numpy()
+        ob, os_, ol = [], [], []
+        for j in range(1, nc):
+            inds = np.nonzero(prob[:, j] > rh.SCORE_THRESH)[0]
+            if not len(inds):
+                continue
+            bj = box_decode(reg[inds, 7 * j:7 * j + 7], np.asarray(proposals, np.float32)[inds], rh.BBOX_REG_WEIGHTS)
+            keep = nms_clamped(bj, prob[inds, j], rh.NMS, rh.NMS_AUG_THICKNESS_Y_Z, 500)
+            ob.append(bj[keep]); os_.append(prob[inds, j][keep]); ol.append(np.full(len(keep), j))
+        if not ob:
+            return np.zeros((0, 7), np.float32), np.zeros(0, np.float32), np.zeros(0, np.int64)
+        b, s, l = np.concatenate(ob), np.concatenate(os_), np.concatenate(ol)
+        if len(s) > rh.DETECTIONS_PER_IMG > 0:
+            th = np.sort(s)[len(s) - rh.DETECTIONS_PER_IMG]
+            k = s >= th
+            b, s, l = b[k], s[k], l[k]
+        return b, s, l
+
+    def __call__(self, coords, feats):
+        rpn_maps, roi_maps = self.fpn(coords, feats)
+        props, _ = self.rpn(rpn_maps)
+        props = props.copy()
+        props[:, 3:6] = np.maximum(props[:, 3:6], 0.001)
+        logits, reg = self.box_head(self.pool(roi_maps, props))
+        return self.post(logits, reg, props)

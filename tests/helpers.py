@@ -25,83 +25,7 @@ def nbr_to_rules(nbr):
     return np.stack([nbr[out_ids, ks], out_ids, ks], 1)
 
 
-class OracleFPN:
-    """FPN_Net forward (SparseConvNet/sparseconvnet/fpn_net.py:140-203) composed from oracle ops,
-    driven by a state_dict with the reference's key names.  eval mode, track_running_stats=False:
-    every BN normalises with the batch mean / unbiased variance (batchNormalization.py:51-56)."""
-
-    def __init__(self, sd, full_scale, n_scales, fpn_scales_from_top, roi_scales_from_top,
-                 rpn_3d_2d_selector, eps=1e-4, leakiness=0.0):
-        self.sd = {k: v.detach().cpu().numpy() for k, v in sd.items()}
-        self.full = np.asarray(full_scale)
-        self.n_scales = n_scales
-        self.fpn, self.roi, self.sel = list(fpn_scales_from_top), list(roi_scales_from_top), list(rpn_3d_2d_selector)
-        self.eps, self.leak = eps, leakiness
-
-    def w(self, key):
-        w = self.sd[key]
-        return w.reshape(w.shape[0], w.shape[2], w.shape[3])
-
-    def bn(self, x, prefix):
-        mean = x.mean(0, dtype=np.float64).astype(np.float32)
-        var = x.var(0, ddof=1, dtype=np.float64).astype(np.float32)
-        out, *_ = oracle.bn_forward(x, mean, var, self.sd[prefix + ".weight"], self.sd[prefix + ".bias"],
-                                    self.eps, 0.0, False, self.leak)
-        return out
-
-    def subm(self, x, loc, key, filt=(3, 3, 3)):
-        ck = (id(loc), tuple(filt))
-        if ck not in self._nbr:
-            self._nbr[ck] = oracle.subm_nbr(loc, filt)[0]
-        return oracle.nbr_conv(x, self.w(key), self._nbr[ck])
-
-    def __call__(self, coords, feats):
-        self._nbr = {}
-        sop, loc0 = oracle.input_sites(coords)
-        x = oracle.input_forward(feats, sop, loc0.shape[0], True)
-        x = self.subm(x, loc0, "layers_in.1.weight")
-        locs, rules, downs = [loc0], [], []
-        for k in range(self.n_scales):
-            if k > 0:
-                pre = f"m_downs.{k}.0"
-                y = self.bn(x, pre + ".0")
-                size = self.full // (2 ** k)
-                lo, ru = oracle.conv_rules(locs[-1], [2, 2, 2], [2, 2, 2], size)
-                locs.append(lo)
-                rules.append(ru)
-                x = oracle.rule_conv(y, self.w(pre + ".1.weight"), ru, lo.shape[0])
-                blk = f"m_downs.{k}.1.1"
-            else:
-                blk = "m_downs.0.0.1"
-            y = self.bn(x, blk + ".0")
-            y = self.subm(y, locs[k], blk + ".1.weight")
-            y = self.bn(y, blk + ".2")
-            y = self.subm(y, locs[k], blk + ".3.weight")
-            x = x + y
-            downs.append(x)
-        top = self.n_scales - 1
-        net = self.subm(downs[top], locs[top], f"m_shortcuts.{top}.weight", (1, 1, 1))
-        ups = [net]
-        need = max(self.fpn + self.roi)
-        for k in range(need):
-            j = self.n_scales - 2 - k
-            y = self.bn(net, f"m_ups.{k}.0")
-            y = oracle.rule_conv(y, self.w(f"m_ups.{k}.1.weight"), rules[j], locs[j].shape[0], deconv=True)
-            sc = self.subm(downs[j], locs[j], f"m_shortcuts.{j}.weight", (1, 1, 1))
-            net = y + sc
-            ups.append(self.subm(net, locs[j], f"m_mergeds.{k}.weight"))
-        up_locs = [locs[self.n_scales - 1 - i] for i in range(len(ups))]
-        maps3d = [(ups[i], up_locs[i]) for i in self.fpn]
-        maps2d = []
-        for i, (f, lo) in enumerate(maps3d):
-            size = self.full // (2 ** (self.n_scales - 1 - self.fpn[i]))
-            z = int(size[2])
-            lo2, ru2 = oracle.conv_rules(lo, [1, 1, z], [1, 1, 1], [size[0], size[1], 1])
-            maps2d.append((oracle.rule_conv(f, self.w(f"convs_pro2d.{i}.weight"), ru2, lo2.shape[0]), lo2))
-        allmaps = maps3d + maps2d
-        rpn = [allmaps[i] for i in self.sel]
-        roi = [(ups[i], up_locs[i]) for i in self.roi]
-        return rpn, roi
+from oracle.detector_port import OracleDetector, OracleFPN  # noqa: E402,F401
 
 
 def sort_by_loc(feats, loc):

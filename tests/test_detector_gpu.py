@@ -1,0 +1,96 @@
+"""Staged GPU parity of the detector tail (RPN head -> anchors -> top-k -> decode -> NMS -> RoIAlign
+-> box head -> per-class NMS) against the CPU port.  A random-init network gives near-tied scores, so
+each stage is checked on the GPU's own input to that stage (top-k membership of near-ties is not a
+property either implementation defines)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle.detector_port import OracleDetector, nms_clamped
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup(dev):
+    from detection_3d_amd.config import get_cfg
+    from detection_3d_amd.detector import build_detection_model
+    from detection_3d_amd.synthetic import make_scene
+    from detection_3d_amd.voxelize import voxelize
+    cfg = get_cfg("4c_Fpn432")
+    torch.manual_seed(1)
+    model = build_detection_model(cfg).to(dev).eval()
+    with torch.no_grad():                       # spread the scores so that NMS / thresholds bite
+        model.rpn.head.cls_logits.weight.mul_(60)
+        model.rpn.head.bbox_pred.weight.mul_(20)
+        model.roi_heads.box.predictor.cls_score.weight.mul_(40)
+        model.roi_heads.box.predictor.bbox_pred.weight.mul_(100)
+    pcl = make_scene(3, 40000)
+    coords, feats = voxelize(torch.from_numpy(pcl).to(dev), 50, cfg.SPARSE3D.VOXEL_FULL_SCALE)
+    c_ref, f_ref = oracle.voxelize(pcl, 50, cfg.SPARSE3D.VOXEL_FULL_SCALE)
+    assert np.array_equal(coords.cpu().numpy(), c_ref) and np.array_equal(feats.cpu().numpy(), f_ref)
+    result, mid = model([coords, feats], return_intermediates=True)
+    return cfg, model, OracleDetector(model.state_dict(), cfg), result, mid
+
+
+def test_rpn_head_and_anchors(setup):
+    cfg, model, orc, result, mid = setup
+    feats = [f.features for f in mid["rpn_features"]]
+    obj, reg = model.rpn.head(feats)
+    maps = [(f.features.cpu().numpy(), f.get_spatial_locations().cpu().numpy()) for f in mid["rpn_features"]]
+    from oracle.detector_port import _lin
+    import torch.nn.functional as F
+    wo, wr = [], []
+    for f, _ in maps:
+        t = F.relu(_lin(orc.sd, "rpn.head.conv", torch.from_numpy(f)))
+        wo.append(_lin(orc.sd, "rpn.head.cls_logits", t).reshape(-1))
+        wr.append(_lin(orc.sd, "rpn.head.bbox_pred", t).reshape(-1, 7))
+    assert torch.allclose(obj.reshape(-1).cpu(), torch.cat(wo), rtol=1e-3, atol=1e-4)
+    assert torch.allclose(reg.cpu(), torch.cat(wr), rtol=1e-3, atol=1e-4)
+    anchors = torch.cat(model.rpn.anchor_generator(mid["rpn_features"]), 0).cpu().numpy()
+    assert np.array_equal(anchors, orc.anchors([l for _, l in maps]))
+    assert anchors.shape[0] == obj.shape[0] == 4 * sum(m[1].shape[0] for m in maps)
+
+
+def test_rpn_decode_and_nms_exact(setup, dev):
+    cfg, model, orc, result, mid = setup
+    from detection_3d_amd import box_ops
+    obj, reg = model.rpn.head([f.features for f in mid["rpn_features"]])
+    anchors = torch.cat(model.rpn.anchor_generator(mid["rpn_features"]), 0)
+    scores = obj.reshape(-1).sigmoid()
+    sk, idx = scores.topk(min(2000, scores.shape[0]), sorted=True)
+    props = box_ops.box_decode(reg[idx], anchors[idx])
+    want = oracle.box_decode(reg[idx].cpu().numpy(), anchors[idx].cpu().numpy())
+    assert np.array_equal(props.cpu().numpy(), want)
+    keep = box_ops.nms_3d_clamped(props, sk, 0.5, [0.3, 0.3], max_proposals=1000, flag="rpn_post").cpu().numpy()
+    wkeep = nms_clamped(want, sk.cpu().numpy(), 0.5, [0.3, 0.3], 1000)
+    assert np.array_equal(keep, wkeep)
+    assert 10 < len(keep) < 2000
+    assert np.array_equal(mid["proposals"].cpu().numpy()[:, :3], want[wkeep][:, :3])
+
+
+def test_roi_pool_box_head_and_postprocess(setup, dev):
+    cfg, model, orc, result, mid = setup
+    props = mid["proposals"]
+    fe = model.roi_heads.box.feature_extractor
+    p = props.clone()
+    p[:, 0:6] *= 50
+    pooled = fe.pooler(mid["roi_features"], p)
+    roi_w = [(f.features.cpu().numpy(), f.get_spatial_locations().cpu().numpy(), None) for f in mid["roi_features"]]
+    want_pooled = orc.pool(roi_w, props.cpu().numpy())
+    assert pooled.shape == want_pooled.shape
+    assert np.abs(pooled.cpu().numpy() - want_pooled).max() < 1e-5 * max(1, np.abs(want_pooled).max())
+    x = fe(mid["roi_features"], props)
+    logits, reg = model.roi_heads.box.predictor(x)
+    wl, wr = orc.box_head(want_pooled)
+    assert torch.allclose(logits.cpu(), wl, rtol=2e-3, atol=2e-4)
+    assert torch.allclose(reg.cpu(), wr, rtol=2e-3, atol=2e-4)
+    # post-processing on identical inputs: survivor sets exact, boxes bit exact
+    got = model.roi_heads.box.post_processor(logits, reg, props)
+    wb, ws, wlab = orc.post(logits.cpu(), reg.cpu(), props.cpu().numpy())
+    assert got["bbox3d"].shape[0] == wb.shape[0] > 0
+    assert np.array_equal(got["labels"].cpu().numpy(), wlab)
+    assert np.array_equal(got["bbox3d"].cpu().numpy(), wb)
+    assert np.allclose(got["scores"].cpu().numpy(), ws, atol=1e-6)
+    assert got["bbox3d"].shape[0] <= cfg.MODEL.ROI_HEADS.DETECTIONS_PER_IMG + 5
