@@ -68,7 +68,10 @@ class AnchorGenerator(nn.Module):
         for base, fmap, stride in zip(self.cell_anchors, feature_maps_sparse, self.strides):
             loc = fmap.get_spatial_locations()
             dev = loc.device
-            cent = loc[:, 0:3].float() / self.voxel_scale * stride.to(dev).view(1, 3)     # :99
+            # :99.  The reference evaluates this on the CPU (true division); a GPU tensor divisor keeps
+            # torch from rewriting x / 50 as x * (1 / 50), which differs in the last bit.
+            vs = torch.full((1, 1), float(self.voxel_scale), dtype=torch.float32, device=dev)
+            cent = loc[:, 0:3].float() / vs * stride.to(dev).view(1, 3)
             cent = torch.cat([cent, torch.zeros(cent.shape[0], 4, device=dev)], 1).view(-1, 1, 7)
             anchors.append((cent + base.to(dev).view(1, -1, 7)).reshape(-1, 7))
         return anchors

@@ -37,7 +37,8 @@ def setup(dev):
 def test_rpn_head_and_anchors(setup):
     cfg, model, orc, result, mid = setup
     feats = [f.features for f in mid["rpn_features"]]
-    obj, reg = model.rpn.head(feats)
+    with torch.no_grad():
+        obj, reg = model.rpn.head(feats)
     maps = [(f.features.cpu().numpy(), f.get_spatial_locations().cpu().numpy()) for f in mid["rpn_features"]]
     from oracle.detector_port import _lin
     import torch.nn.functional as F
@@ -56,7 +57,8 @@ def test_rpn_head_and_anchors(setup):
 def test_rpn_decode_and_nms_exact(setup, dev):
     cfg, model, orc, result, mid = setup
     from detection_3d_amd import box_ops
-    obj, reg = model.rpn.head([f.features for f in mid["rpn_features"]])
+    with torch.no_grad():
+        obj, reg = model.rpn.head([f.features for f in mid["rpn_features"]])
     anchors = torch.cat(model.rpn.anchor_generator(mid["rpn_features"]), 0)
     scores = obj.reshape(-1).sigmoid()
     sk, idx = scores.topk(min(2000, scores.shape[0]), sorted=True)
@@ -76,13 +78,15 @@ def test_roi_pool_box_head_and_postprocess(setup, dev):
     fe = model.roi_heads.box.feature_extractor
     p = props.clone()
     p[:, 0:6] *= 50
-    pooled = fe.pooler(mid["roi_features"], p)
+    with torch.no_grad():
+        pooled = fe.pooler(mid["roi_features"], p)
     roi_w = [(f.features.cpu().numpy(), f.get_spatial_locations().cpu().numpy(), None) for f in mid["roi_features"]]
     want_pooled = orc.pool(roi_w, props.cpu().numpy())
     assert pooled.shape == want_pooled.shape
     assert np.abs(pooled.cpu().numpy() - want_pooled).max() < 1e-5 * max(1, np.abs(want_pooled).max())
-    x = fe(mid["roi_features"], props)
-    logits, reg = model.roi_heads.box.predictor(x)
+    with torch.no_grad():
+        x = fe(mid["roi_features"], props)
+        logits, reg = model.roi_heads.box.predictor(x)
     wl, wr = orc.box_head(want_pooled)
     assert torch.allclose(logits.cpu(), wl, rtol=2e-3, atol=2e-4)
     assert torch.allclose(reg.cpu(), wr, rtol=2e-3, atol=2e-4)

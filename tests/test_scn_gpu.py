@@ -198,7 +198,7 @@ def test_fpn_backbone_vs_oracle(dev, fuse, skip):
     rpn, roi = net([torch.from_numpy(coords), torch.from_numpy(feats).to(dev)])
     orc = OracleFPN(net.state_dict(), size, 5, [2, 1], [2, 1], [1, 2, 3])
     rpn_w, roi_w = orc(coords, feats)
-    for got, (wf, wl) in list(zip(rpn, rpn_w)) + list(zip(roi, roi_w)):
+    for got, (wf, wl) in list(zip(rpn, rpn_w)) + list(zip(roi, [r[:2] for r in roi_w])):
         gl = got.get_spatial_locations().cpu().numpy()
         gf, gl = sort_by_loc(got.features.cpu().numpy(), gl)
         wf, wl = sort_by_loc(wf, wl)
