@@ -276,6 +276,7 @@ __global__ __launch_bounds__(256) void k_iou_matrix(IouArgs a) {
 struct NmsBox {
   Quad q;
   float d0, d1, z0, z1, raw[5];
+  float radius;  // BEV circumscribed circle, for the exact far-apart early-out
   double area;
 };
 __global__ void k_nms_prep(const float *__restrict__ boxes, int n, NmsBox *__restrict__ rec) {
@@ -287,41 +288,51 @@ __global__ void k_nms_prep(const float *__restrict__ boxes, int n, NmsBox *__res
   r.z0 = b[2]; r.z1 = b[2] + b[5];
   r.raw[0] = b[0]; r.raw[1] = b[1]; r.raw[2] = b[3]; r.raw[3] = b[4]; r.raw[4] = b[6];
   r.q = make_quad(b[0], b[1], b[3], b[4], b[6]);
+  r.radius = 0.5f * sqrtf(b[3] * b[3] + b[4] * b[4]);
   r.area = quad_area_f64(r.q.p);
   rec[i] = r;
 }
-__global__ __launch_bounds__(64) void k_nms_mask(const NmsBox *__restrict__ rec, int n, int ncb,
-                                                 float thresh,
-                                                 unsigned long long *__restrict__ mask) {
+// 256 threads per 64 x 64 tile: wave w decides rows 16w..16w+15, lanes = candidate boxes j.
+// Two early-outs that cannot change the decision:
+//  * z intervals do not overlap  -> iou_z <= 0 (or NaN) -> gate `iou3d > 0` is false;
+//  * BEV circumscribed circles are disjoint (with a 0.1 % + 1e-4 margin, far above fp32 rounding of
+//    metre-sized boxes) -> no corner lies inside the other box and no edges cross -> area 0 -> gate false.
+__global__ __launch_bounds__(256) void k_nms_mask(const NmsBox *__restrict__ rec, int n, int ncb,
+                                                  float thresh,
+                                                  unsigned long long *__restrict__ mask) {
   const int rt = blockIdx.y, ct = blockIdx.x;
   if (ct < rt) return;
   __shared__ NmsBox srow[64];
-  const int lane = threadIdx.x;
-  if (rt * 64 + lane < n) srow[lane] = rec[rt * 64 + lane];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < 64 && rt * 64 + threadIdx.x < n) srow[threadIdx.x] = rec[rt * 64 + threadIdx.x];
   const int j = ct * 64 + lane;
   NmsBox cb;
   if (j < n) cb = rec[j];
   __syncthreads();
   const int nrow = min(64, n - rt * 64);
-  for (int ii = 0; ii < nrow; ii++) {
+  for (int ii = wave * 16; ii < min(nrow, wave * 16 + 16); ii++) {
     const int i = rt * 64 + ii;
     bool sup = false;
     if (j < n && j > i) {
       const NmsBox &rb = srow[ii];
-      // gate = boxes_iou_3d(dets, dets)[i, j] > 0 (nms_cpu.py:35, spconv nms.h)
-      float v = iou_eval(cb.q, cb.d0, cb.d1, rb.q, rb.d0, rb.d1, -1);
-      bool same = true;
-#pragma unroll
-      for (int d = 0; d < 5; d++) same = same && (fabsf(rb.raw[d] - cb.raw[d]) < (float)1e-6);
-      if (same) v = 1.f;
       const float overlap = fminf(cb.z1, rb.z1) - fmaxf(cb.z0, rb.z0);
-      const float common = fmaxf(cb.z1, rb.z1) - fminf(cb.z0, rb.z0);
-      v = v * (overlap / common);
-      if (v > 0.0f) {
-        const double ia = quad_inter_f64(rb.q.p, cb.q.p);
-        if (ia > 0) {
-          const double ua = rb.area + cb.area - ia;
-          sup = ua > 0 && ia / ua >= (double)thresh;
+      const float dx = cb.raw[0] - rb.raw[0], dy = cb.raw[1] - rb.raw[1];
+      const float rr = (cb.radius + rb.radius) * 1.001f + 1e-4f;
+      if (overlap > 0.f && dx * dx + dy * dy <= rr * rr) {
+        // gate = boxes_iou_3d(dets, dets)[i, j] > 0 (nms_cpu.py:35, spconv nms.h)
+        float v = iou_eval(cb.q, cb.d0, cb.d1, rb.q, rb.d0, rb.d1, -1);
+        bool same = true;
+#pragma unroll
+        for (int d = 0; d < 5; d++) same = same && (fabsf(rb.raw[d] - cb.raw[d]) < (float)1e-6);
+        if (same) v = 1.f;
+        const float common = fmaxf(cb.z1, rb.z1) - fminf(cb.z0, rb.z0);
+        v = v * (overlap / common);
+        if (v > 0.0f) {
+          const double ia = quad_inter_f64(rb.q.p, cb.q.p);
+          if (ia > 0) {
+            const double ua = rb.area + cb.area - ia;
+            sup = ua > 0 && ia / ua >= (double)thresh;
+          }
         }
       }
     }
@@ -330,8 +341,8 @@ __global__ __launch_bounds__(64) void k_nms_mask(const NmsBox *__restrict__ rec,
   }
 }
 // Greedy sweep by ONE wave: lane w owns word w of the "removed" bit vector.  Per 64-box chunk the
-// intra-chunk chain is resolved on the diagonal words with readlane, then the kept rows' words
-// are OR-ed in with independent loads.
+// intra-chunk chain is resolved on the diagonal words with readlane; the chunk's 64 mask rows are
+// loaded unconditionally (independent loads, pipelined) and OR-ed in for the kept boxes.
 __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long *__restrict__ mask, int n,
                                                   int ncb, int32_t *__restrict__ keep,
                                                   int32_t *__restrict__ n_keep) {
@@ -353,13 +364,25 @@ __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long *__re
         alive &= ~d;
       }
     }
+    const bool mine = lane > c && lane < ncb;  // words left of the diagonal are never read again
+#pragma unroll 1
+    for (int b0 = 0; b0 < 64; b0 += 16) {
+      unsigned long long w[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const int b = b0 + u;
+        w[u] = (mine && b < nrow) ? mask[(size_t)(base + b) * ncb + lane] : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; u++)
+        if ((kept >> (b0 + u)) & 1ull) removed |= w[u];
+    }
     unsigned long long k = kept;
     while (k) {
       const int b = __builtin_ctzll(k);
       k &= k - 1;
       if (lane == 0) keep[cnt] = base + b;
       cnt++;
-      if (lane >= c && lane < ncb) removed |= mask[(size_t)(base + b) * ncb + lane];
     }
   }
   if (lane == 0) *n_keep = cnt;
@@ -447,7 +470,7 @@ int d3d_rotate_nms_3d_sorted(const float *boxes, int n, float thresh, int32_t *k
   unsigned long long *mask = (unsigned long long *)scratch;
   NmsBox *rec = (NmsBox *)((char *)scratch + (((size_t)n * ncb * 8 + 255) & ~size_t(255)));
   hipLaunchKernelGGL(k_nms_prep, dim3((n + 127) / 128), dim3(128), 0, s, boxes, n, rec);
-  hipLaunchKernelGGL(k_nms_mask, dim3(ncb, ncb), dim3(64), 0, s, rec, n, ncb, thresh, mask);
+  hipLaunchKernelGGL(k_nms_mask, dim3(ncb, ncb), dim3(256), 0, s, rec, n, ncb, thresh, mask);
   hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(64), 0, s, mask, n, ncb, keep, n_keep);
   D3D_LAUNCH_CHECK();
   return D3D_OK;

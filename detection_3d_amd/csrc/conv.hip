@@ -9,6 +9,8 @@
 // (k-interleaved packed weights, L2-resident) read straight from global memory.  Accumulators
 // stay in registers across all offsets; every output row is written exactly once (no atomics,
 // deterministic, independent of how rows are grouped).
+#include <algorithm>
+
 #include "d3d_internal.h"
 
 namespace d3d {
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
     const float *__restrict__ in, int cin, const float *__restrict__ wp,
     const int32_t *__restrict__ nbrT, int npos, const int32_t *__restrict__ rows,
     const uint32_t *__restrict__ blkmask, int n_blk, const float *__restrict__ residual,
-    float *__restrict__ out) {
+    float *__restrict__ out, int n_split, float *__restrict__ partial) {
   constexpr int WPBLK = COUT / 32 / NT;
   static_assert(WPBLK == 1 || BPW == 1, "row blocks sharing a workgroup must be single-wave");
   constexpr int TPB = WPBLK * 64;  // threads working on one row block
@@ -85,6 +87,15 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
   };
 
   uint32_t mask = blkmask[blk];
+  if (n_split > 1) {
+    // offset-split launch (few rows): this workgroup keeps every n_split-th active offset and
+    // writes a partial tile; k_conv_reduce sums the partials in a fixed order.
+    uint32_t keep = 0;
+    int ord = 0;
+    for (uint32_t m = mask; m; m &= m - 1, ord++)
+      if (ord % n_split == (int)blockIdx.y) keep |= m & (~m + 1);
+    mask = keep;
+  }
   const int rowid = rows[blk * 32 + r];
   f32x16 acc[NT];
 #pragma unroll
@@ -163,6 +174,16 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
     ct = nct;
   }
   // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
+  if (n_split > 1) {
+    float *pt = partial + ((size_t)blockIdx.y * npos + (size_t)blk * 32) * COUT;
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+      const int row_in = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) pt[(size_t)row_in * COUT + colbase + nt * 32 + r] = acc[nt][reg];
+    }
+    return;
+  }
 #pragma unroll
   for (int reg = 0; reg < 16; reg++) {
     const int row_in = (reg & 3) + 8 * (reg >> 2) + 4 * h;
@@ -178,40 +199,79 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
   }
 }
 
+// out[rows[pos]] = sum_y partial[y][pos] (+ residual), y in increasing order
+__global__ __launch_bounds__(256) void k_conv_reduce(const float *__restrict__ partial, int n_split,
+                                                     int npos, int cout4, const int32_t *__restrict__ rows,
+                                                     const float *__restrict__ residual,
+                                                     float *__restrict__ out) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)npos * cout4) return;
+  const int pos = (int)(t / cout4), c4 = (int)(t % cout4);
+  const int orow = rows[pos];
+  if (orow < 0) return;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int y = 0; y < n_split; y++) acc += *(const f32x4 *)(partial + (((size_t)y * npos + pos) * cout4 + c4) * 4);
+  const size_t o = ((size_t)orow * cout4 + c4) * 4;
+  if (residual) acc += *(const f32x4 *)(residual + o);
+  *(f32x4 *)(out + o) = acc;
+}
+
+static constexpr int kSplitTargetWaves = 2048;  // below this many waves the launch is offset-split
+
 template <int CT, int NCT, int COUT, int NT, int BPW>
-static int launch_t(const Plan &p, const float *in, int cin, const float *wp, const float *residual,
-                    float *out, hipStream_t s) {
-  constexpr int threads = BPW * (COUT / 32 / NT) * 64;
-  dim3 grid((p.n_blk + BPW - 1) / BPW);
-  hipLaunchKernelGGL((k_conv<CT, NCT, COUT, NT, BPW>), grid, dim3(threads), 0, s, in, cin, wp, p.nbrT,
-                     p.n_blk * 32, p.rows, p.blkmask, p.n_blk, residual, out);
+static int launch_t(d3d_meta *m, const Plan &p, const float *in, int cin, const float *wp,
+                    const float *residual, float *out, hipStream_t s) {
+  constexpr int WPBLK = COUT / 32 / NT;
+  constexpr int threads = BPW * WPBLK * 64;
+  const int npos = p.n_blk * 32;
+  int n_split = 1;
+  if (BPW == 1 && p.K > 1 && m) {
+    const long waves = (long)p.n_blk * WPBLK;
+    if (waves < kSplitTargetWaves) n_split = (int)std::min<long>(p.K, (kSplitTargetWaves + waves - 1) / waves);
+  }
+  float *partial = nullptr;
+  size_t mark = 0;
+  if (n_split > 1) {
+    mark = m->arena.used;
+    partial = m->arena.get<float>((size_t)n_split * npos * COUT);
+    if (!partial) n_split = 1;  // arena full: fall back to the unsplit launch
+  }
+  dim3 grid((p.n_blk + BPW - 1) / BPW, n_split);
+  hipLaunchKernelGGL((k_conv<CT, NCT, COUT, NT, BPW>), grid, dim3(threads), 0, s, in, cin, wp, p.nbrT, npos,
+                     p.rows, p.blkmask, p.n_blk, residual, out, n_split, partial);
+  if (n_split > 1) {
+    const long total = (long)npos * (COUT / 4);
+    hipLaunchKernelGGL(k_conv_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, partial, n_split,
+                       npos, COUT / 4, p.rows, residual, out);
+    m->arena.used = mark;  // stream-ordered scratch
+  }
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }
 
 template <int CT, int NCT>
-static int launch_c(const Plan &p, const float *in, int cin, const float *wp, int cout,
+static int launch_c(d3d_meta *m, const Plan &p, const float *in, int cin, const float *wp, int cout,
                     const float *residual, float *out, hipStream_t s) {
   switch (cout) {
-    case 32: return launch_t<CT, NCT, 32, 1, 4>(p, in, cin, wp, residual, out, s);    // 4 independent waves
-    case 64: return launch_t<CT, NCT, 64, 1, 1>(p, in, cin, wp, residual, out, s);    // 2 waves / block
-    case 128: return launch_t<CT, NCT, 128, 1, 1>(p, in, cin, wp, residual, out, s);  // 4 waves / block
-    case 256: return launch_t<CT, NCT, 256, 1, 1>(p, in, cin, wp, residual, out, s);  // 8 waves / block
+    case 32: return launch_t<CT, NCT, 32, 1, 4>(m, p, in, cin, wp, residual, out, s);    // 4 independent waves
+    case 64: return launch_t<CT, NCT, 64, 1, 1>(m, p, in, cin, wp, residual, out, s);    // 2 waves / block
+    case 128: return launch_t<CT, NCT, 128, 1, 1>(m, p, in, cin, wp, residual, out, s);  // 4 waves / block
+    case 256: return launch_t<CT, NCT, 256, 1, 1>(m, p, in, cin, wp, residual, out, s);  // 8 waves / block
   }
   set_error("convolution: Cout=%d not supported (32, 64, 128, 256)", cout);
   return D3D_ERR_UNSUPPORTED;
 }
 
-int launch_conv(const Plan &p, const float *in, int cin, const float *packed_w, int cout,
+int launch_conv(d3d_meta *m, const Plan &p, const float *in, int cin, const float *packed_w, int cout,
                 const float *residual, float *out, hipStream_t s) {
   if (p.n_rows == 0) return D3D_OK;
   D3D_REQUIRE(in && packed_w && out, "convolution: null pointer");
   switch (padded_cin(cin)) {
-    case 16: return launch_c<16, 1>(p, in, cin, packed_w, cout, residual, out, s);
-    case 32: return launch_c<32, 1>(p, in, cin, packed_w, cout, residual, out, s);
-    case 64: return launch_c<64, 1>(p, in, cin, packed_w, cout, residual, out, s);
-    case 128: return launch_c<128, 1>(p, in, cin, packed_w, cout, residual, out, s);
-    case 256: return launch_c<128, 2>(p, in, cin, packed_w, cout, residual, out, s);
+    case 16: return launch_c<16, 1>(m, p, in, cin, packed_w, cout, residual, out, s);
+    case 32: return launch_c<32, 1>(m, p, in, cin, packed_w, cout, residual, out, s);
+    case 64: return launch_c<64, 1>(m, p, in, cin, packed_w, cout, residual, out, s);
+    case 128: return launch_c<128, 1>(m, p, in, cin, packed_w, cout, residual, out, s);
+    case 256: return launch_c<128, 2>(m, p, in, cin, packed_w, cout, residual, out, s);
   }
   set_error("convolution: Cin=%d not supported (<= 256)", cin);
   return D3D_ERR_UNSUPPORTED;
@@ -248,7 +308,7 @@ int d3d_subm_conv_forward(d3d_meta *m, const int *size, const int *filt, const f
   if (rc) return rc;
   const Plan *p = find_plan(m, 0, size, filt, nullptr);
   if (macs_host) *macs_host = (double)p->n_rules * cin * cout;
-  return launch_conv(*p, in, cin, packed_w, cout, residual, out, s);
+  return launch_conv(m, *p, in, cin, packed_w, cout, residual, out, s);
 }
 
 int d3d_conv_forward(d3d_meta *m, const int *in_size, const int *out_size, const int *filt,
@@ -260,7 +320,7 @@ int d3d_conv_forward(d3d_meta *m, const int *in_size, const int *out_size, const
   if (rc) return rc;
   const Plan *p = find_plan(m, 1, in_size, filt, stride);
   if (macs_host) *macs_host = (double)p->n_rules * cin * cout;
-  return launch_conv(*p, in, cin, packed_w, cout, nullptr, out, s);
+  return launch_conv(m, *p, in, cin, packed_w, cout, nullptr, out, s);
 }
 
 // Deconvolution: in = coarse features, out = fine features; reuses the strided rulebook of the
@@ -274,7 +334,7 @@ int d3d_deconv_forward(d3d_meta *m, const int *in_size, const int *out_size, con
   int rc = get_deconv_plan(m, out_size, filt, stride, s, &p);
   if (rc) return rc;
   if (macs_host) *macs_host = (double)p->n_rules * cin * cout;
-  return launch_conv(*p, in, cin, packed_w, cout, residual, out, s);
+  return launch_conv(m, *p, in, cin, packed_w, cout, residual, out, s);
 }
 
 }  // extern "C"

@@ -121,7 +121,7 @@ int get_deconv_plan(d3d_meta *m, const int *fine_size, const int *filt, const in
                     hipStream_t s, const Plan **out);
 
 // conv.hip
-int launch_conv(const Plan &p, const float *in, int cin, const float *packed_w, int cout,
+int launch_conv(d3d_meta *m, const Plan &p, const float *in, int cin, const float *packed_w, int cout,
                 const float *residual, float *out, hipStream_t s);
 
 __device__ __forceinline__ uint64_t pack_key(int b, int x, int y, int z) {
