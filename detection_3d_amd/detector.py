@@ -200,11 +200,23 @@ class FPN2MLPFeatureExtractor(nn.Module):
             nn.init.kaiming_uniform_(l.weight, a=1)
             nn.init.constant_(l.bias, 0)
 
+    def _head_conv(self, pooled):
+        """conv3d (kernel [1,1,pz] over a z extent of exactly pz) + BatchNorm3d + ReLU.  The convolution
+        is one [K*ph*pw, C*pz] x [C*pz, rep] GEMM (rocBLAS) instead of a MIOpen conv3d search."""
+        conv, bn, relu = self.conv3d[0], self.conv3d[1], self.conv3d[2]
+        K, C, ph, pw, pz = pooled.shape
+        if tuple(conv.kernel_size) == (1, 1, pz) and tuple(conv.stride) == (1, 1, 1):
+            a = pooled.permute(0, 2, 3, 1, 4).reshape(K * ph * pw, C * pz)
+            y = torch.addmm(conv.bias, a, conv.weight.view(conv.out_channels, C * pz).t())
+            y = y.view(K, ph, pw, conv.out_channels, 1).permute(0, 3, 1, 2, 4)
+            return relu(bn(y.contiguous()))
+        return self.conv3d(pooled)
+
     def forward(self, x0, proposals):
         p = proposals.clone()
         p[:, 0:6] *= self.voxel_scale                                           # convert_metric_to_pixel
-        x1 = self.conv3d(self.pooler(x0, p))
-        x2 = x1.view(x1.size(0), -1)
+        x1 = self._head_conv(self.pooler(x0, p))
+        x2 = x1.reshape(x1.size(0), -1)
         return F.relu(self.fc7(F.relu(self.fc6(x2))))
 
 
