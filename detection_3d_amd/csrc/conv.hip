@@ -306,8 +306,13 @@ int d3d_subm_conv_forward(d3d_meta *m, const int *size, const int *filt, const f
   D3D_REQUIRE(m && size && filt, "null argument");
   int rc = d3d_subm_prepare(m, size, filt, stream, nullptr);
   if (rc) return rc;
-  const Plan *p = find_plan(m, 0, size, filt, nullptr);
-  if (macs_host) *macs_host = (double)p->n_rules * cin * cout;
+  Plan *p = const_cast<Plan *>(find_plan(m, 0, size, filt, nullptr));
+  if (macs_host) {
+    long nr;
+    rc = plan_rules(m, *p, s, &nr);
+    if (rc) return rc;
+    *macs_host = (double)nr * cin * cout;
+  }
   return launch_conv(m, *p, in, cin, packed_w, cout, residual, out, s);
 }
 
@@ -318,8 +323,13 @@ int d3d_conv_forward(d3d_meta *m, const int *in_size, const int *out_size, const
   D3D_REQUIRE(m && in_size && out_size && filt && stride, "null argument");
   int rc = d3d_conv_prepare(m, in_size, out_size, filt, stride, stream, nullptr, nullptr);
   if (rc) return rc;
-  const Plan *p = find_plan(m, 1, in_size, filt, stride);
-  if (macs_host) *macs_host = (double)p->n_rules * cin * cout;
+  Plan *p = const_cast<Plan *>(find_plan(m, 1, in_size, filt, stride));
+  if (macs_host) {
+    long nr;
+    rc = plan_rules(m, *p, s, &nr);
+    if (rc) return rc;
+    *macs_host = (double)nr * cin * cout;
+  }
   return launch_conv(m, *p, in, cin, packed_w, cout, nullptr, out, s);
 }
 
@@ -333,7 +343,12 @@ int d3d_deconv_forward(d3d_meta *m, const int *in_size, const int *out_size, con
   const Plan *p = nullptr;
   int rc = get_deconv_plan(m, out_size, filt, stride, s, &p);
   if (rc) return rc;
-  if (macs_host) *macs_host = (double)p->n_rules * cin * cout;
+  if (macs_host) {
+    long nr;
+    rc = plan_rules(m, *const_cast<Plan *>(p), s, &nr);
+    if (rc) return rc;
+    *macs_host = (double)nr * cin * cout;
+  }
   return launch_conv(m, *p, in, cin, packed_w, cout, residual, out, s);
 }
 

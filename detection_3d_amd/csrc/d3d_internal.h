@@ -79,7 +79,8 @@ struct Plan {
   int K = 0;
   int n_rows = 0;
   int n_blk = 0;
-  long n_rules = 0;
+  long n_rules = 0;                           // -1: still on the device (n_rules_dev)
+  unsigned long long *n_rules_dev = nullptr;
   int32_t *rows = nullptr;
   int32_t *nbrT = nullptr;
   uint32_t *blkmask = nullptr;
@@ -115,7 +116,9 @@ int scan_exclusive_i32(const int32_t *in, int32_t *out, int n, int32_t *total_de
                        hipStream_t s);
 int sort_pairs_u32(const uint32_t *keys_in, uint32_t *keys_out, const int32_t *vals_in,
                    int32_t *vals_out, int n, int end_bit, Arena &scratch, hipStream_t s);
-int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan, hipStream_t s);
+int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan, hipStream_t s,
+                  uint32_t *mask_in);
+int plan_rules(d3d_meta *m, Plan &p, hipStream_t s, long *out);
 const Plan *find_plan(d3d_meta *m, int kind, const int *in_size, const int *filt, const int *stride);
 int get_deconv_plan(d3d_meta *m, const int *fine_size, const int *filt, const int *stride,
                     hipStream_t s, const Plan **out);

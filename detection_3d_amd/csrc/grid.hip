@@ -265,20 +265,36 @@ __global__ void k_conv_fill(const int32_t *__restrict__ loc, long n_entries, Con
   nbr_dec[(size_t)i * K + off] = oid;
 }
 
-// a4. Submanifold neighbour probes (SubmanifoldConvolutionRules.h:13-45).
-__global__ void k_subm_nbr(const int32_t *__restrict__ loc, int n, int fx, int fy, int fz,
-                           const uint64_t *__restrict__ keys, const int32_t *__restrict__ vals,
-                           int cap, int32_t *__restrict__ nbr) {
+// a4. Submanifold neighbour probes (SubmanifoldConvolutionRules.h:13-45), one thread per output
+// site: the K probes are independent loads, the row's offset mask and the rule count come for free.
+__global__ __launch_bounds__(256) void k_subm_nbr(const int32_t *__restrict__ loc, int n, int fx, int fy,
+                                                  int fz, const uint64_t *__restrict__ keys,
+                                                  const int32_t *__restrict__ vals, int cap,
+                                                  int32_t *__restrict__ nbr, uint32_t *__restrict__ mask,
+                                                  unsigned long long *n_rules) {
   const int K = fx * fy * fz;
-  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long)n * K) return;
-  int i = (int)(t / K), k = (int)(t % K);
-  int dz = k % fz, dy = (k / fz) % fy, dx = k / (fz * fy);
-  const int32_t *p = loc + (size_t)i * 4;
-  int x = p[0] - fx / 2 + dx, y = p[1] - fy / 2 + dy, z = p[2] - fz / 2 + dz;
-  int v = -1;
-  if (x >= 0 && y >= 0 && z >= 0) v = hash_find(keys, vals, cap, pack_key(p[3], x, y, z));
-  nbr[t] = v;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t m = 0;
+  if (i < n) {
+    const int32_t *p = loc + (size_t)i * 4;
+    const int px = p[0] - fx / 2, py = p[1] - fy / 2, pz = p[2] - fz / 2, pb = p[3];
+    int k = 0;
+    for (int dx = 0; dx < fx; dx++)
+      for (int dy = 0; dy < fy; dy++)
+#pragma unroll 3
+        for (int dz = 0; dz < fz; dz++, k++) {
+          const int x = px + dx, y = py + dy, z = pz + dz;
+          int v = -1;
+          if (x >= 0 && y >= 0 && z >= 0) v = hash_find(keys, vals, cap, pack_key(pb, x, y, z));
+          nbr[(size_t)i * K + k] = v;
+          m |= (v >= 0 ? 1u : 0u) << k;
+        }
+    mask[i] = m;
+  }
+  int c = __popc(m);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(n_rules, (unsigned long long)c);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -325,7 +341,10 @@ __global__ void k_pad_rows(int32_t *rows, int n, int npos) {
   if (i < npos) rows[i] = -1;
 }
 
-int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan, hipStream_t s) {
+// `mask_in` (may be null): per-row offset masks already computed by the caller together with the
+// rule count in plan.n_rules_dev.  The rule count stays on the device until somebody asks for it.
+int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan, hipStream_t s,
+                  uint32_t *mask_in) {
   D3D_REQUIRE(K >= 1 && K <= 32, "filter volume %d not supported (1..32)", K);
   Arena &A = m->arena;
   plan.K = K;
@@ -335,18 +354,28 @@ int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan
   D3D_ALLOC(rows, int32_t, A, (size_t)npos + 1);
   D3D_ALLOC(nbrT, int32_t, A, (size_t)npos * K + 1);
   D3D_ALLOC(blkmask, uint32_t, A, (size_t)plan.n_blk + 1);
-  D3D_ALLOC(cnt, unsigned long long, A, 1);
   plan.rows = rows;
   plan.nbrT = nbrT;
   plan.blkmask = blkmask;
-  plan.n_rules = 0;
+  plan.n_rules = n_rows == 0 ? 0 : -1;
   if (n_rows == 0) return D3D_OK;
+  if (!plan.n_rules_dev) {
+    D3D_ALLOC(cnt, unsigned long long, A, 1);
+    plan.n_rules_dev = cnt;
+    D3D_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), s));
+  }
   size_t mark = A.used;
-  D3D_ALLOC(mask, uint32_t, A, n_rows);
+  uint32_t *mask = mask_in;
+  if (!mask) {
+    mask = A.get<uint32_t>(n_rows);
+    if (!mask) {
+      set_error("metadata arena exhausted while finalising a rulebook");
+      return D3D_ERR_NOMEM;
+    }
+    hipLaunchKernelGGL(k_row_mask, grid1d(n_rows), dim3(256), 0, s, nbr, n_rows, K, mask, plan.n_rules_dev);
+  }
   D3D_ALLOC(mask_sorted, uint32_t, A, n_rows);
   D3D_ALLOC(iota, int32_t, A, n_rows);
-  D3D_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), s));
-  hipLaunchKernelGGL(k_row_mask, grid1d(n_rows), dim3(256), 0, s, nbr, n_rows, K, mask, cnt);
   hipLaunchKernelGGL(k_iota, grid1d(n_rows), dim3(256), 0, s, iota, n_rows);
   int rc = sort_pairs_u32(mask, mask_sorted, iota, rows, n_rows, K, A, s);
   if (rc) return rc;
@@ -355,11 +384,29 @@ int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan
   hipLaunchKernelGGL(k_blk_mask, grid1d((long)plan.n_blk * 64), dim3(256), 0, s, nbrT, npos, K,
                      plan.n_blk, blkmask);
   D3D_LAUNCH_CHECK();
-  D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[0], cnt, sizeof(long), hipMemcpyDeviceToHost, s));
-  D3D_HIP_CHECK(hipStreamSynchronize(s));
-  plan.n_rules = m->host_words[0];
   A.used = mark;  // scratch released (stream-ordered reuse)
   return D3D_OK;
+}
+
+// reads the rule count back (one stream sync) the first time it is asked for
+int plan_rules(d3d_meta *m, Plan &p, hipStream_t s, long *out) {
+  if (p.n_rules < 0) {
+    D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[0], p.n_rules_dev, sizeof(long), hipMemcpyDeviceToHost, s));
+    D3D_HIP_CHECK(hipStreamSynchronize(s));
+    p.n_rules = m->host_words[0];
+  }
+  *out = p.n_rules;
+  return D3D_OK;
+}
+
+__global__ void k_identity_plan(int32_t *rows, int32_t *nbrT, uint32_t *blkmask, int n, int npos, int n_blk) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npos) {
+    int v = i < n ? i : -1;
+    rows[i] = v;
+    nbrT[i] = v;
+  }
+  if (i < n_blk) blkmask[i] = 1u;
 }
 
 static PlanKey make_key(int kind, const int *in_size, const int *filt, const int *stride) {
@@ -390,7 +437,7 @@ int get_deconv_plan(d3d_meta *m, const int *fine_size, const int *filt, const in
     }
     Plan p;
     int K = filt[0] * filt[1] * filt[2];
-    int rc = finalize_plan(m, raw->second.nbr_dec, raw->second.n_in, K, p, s);
+    int rc = finalize_plan(m, raw->second.nbr_dec, raw->second.n_in, K, p, s, nullptr);
     if (rc) return rc;
     it = m->plans.emplace(key, p).first;
   }
@@ -721,24 +768,45 @@ int d3d_subm_prepare(d3d_meta *m, const int *size, const int *filt, void *stream
     // raw table lives above the plan's persistent arrays: allocate persistent part first
     // (finalize_plan), so stage the raw table at the far end of the arena instead.
     size_t raw_bytes = ((size_t)g->n * K + 1) * sizeof(int32_t);
-    if (A.used + 2 * raw_bytes + (1 << 20) > A.cap) {
+    if (A.used + 2 * raw_bytes + (size_t)g->n * 16 + (1 << 20) > A.cap) {
       set_error("metadata arena exhausted while building a submanifold rulebook");
       return D3D_ERR_NOMEM;
     }
-    int32_t *nbr = (int32_t *)(A.base + ((A.cap - raw_bytes) & ~size_t(255)));
-    if (g->n)
-      hipLaunchKernelGGL(k_subm_nbr, grid1d((long)g->n * K), dim3(256), 0, s, g->loc, g->n, filt[0],
-                         filt[1], filt[2], g->keys, g->vals, g->cap, nbr);
-    D3D_LAUNCH_CHECK();
-    int rc;
-    {
-      CapGuard guard(A, (A.cap - raw_bytes) & ~size_t(255));
-      rc = finalize_plan(m, nbr, g->n, K, p, s);
+    if (K == 1) {
+      // 1x1x1 submanifold convolution: every site is its own (only) neighbour -> identity rulebook
+      p.K = 1;
+      p.n_rows = g->n;
+      p.n_blk = (g->n + 31) / 32;
+      p.n_rules = g->n;
+      const int npos = p.n_blk * 32;
+      D3D_ALLOC(rows, int32_t, A, (size_t)npos + 1);
+      D3D_ALLOC(nbrT, int32_t, A, (size_t)npos + 1);
+      D3D_ALLOC(blkmask, uint32_t, A, (size_t)p.n_blk + 1);
+      p.rows = rows;
+      p.nbrT = nbrT;
+      p.blkmask = blkmask;
+      if (npos) hipLaunchKernelGGL(k_identity_plan, grid1d(npos), dim3(256), 0, s, rows, nbrT, blkmask, g->n, npos, p.n_blk);
+      D3D_LAUNCH_CHECK();
+    } else {
+      int32_t *nbr = (int32_t *)(A.base + ((A.cap - raw_bytes) & ~size_t(255)));
+      uint32_t *mask = (uint32_t *)((char *)nbr - (((size_t)g->n * 4 + 511) & ~size_t(255)));
+      D3D_ALLOC(cnt, unsigned long long, A, 1);
+      p.n_rules_dev = cnt;
+      D3D_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), s));
+      if (g->n)
+        hipLaunchKernelGGL(k_subm_nbr, grid1d(g->n), dim3(256), 0, s, g->loc, g->n, filt[0], filt[1], filt[2],
+                           g->keys, g->vals, g->cap, nbr, mask, cnt);
+      D3D_LAUNCH_CHECK();
+      int rc;
+      {
+        CapGuard guard(A, (size_t)((char *)mask - A.base) & ~size_t(255));
+        rc = finalize_plan(m, nbr, g->n, K, p, s, mask);
+      }
+      if (rc) return rc;
     }
-    if (rc) return rc;
     it = m->plans.emplace(key, p).first;
   }
-  if (n_rules_host) *n_rules_host = it->second.n_rules;
+  if (n_rules_host) return plan_rules(m, it->second, s, n_rules_host);
   return D3D_OK;
 }
 
@@ -820,10 +888,10 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
       hipLaunchKernelGGL(k_conv_fill, grid1d(n_entries), dim3(256), 0, s, gi->loc, n_entries, geo, K, eslot, vals, nbr_fwd, nbr_dec);
       D3D_LAUNCH_CHECK();
       A.used = mark;
-      rc = finalize_plan(m, nbr_fwd, n_out, K, p, s);
+      rc = finalize_plan(m, nbr_fwd, n_out, K, p, s, nullptr);
       if (rc) return rc;
     } else {
-      int rc = finalize_plan(m, nullptr, 0, K, p, s);
+      int rc = finalize_plan(m, nullptr, 0, K, p, s, nullptr);
       if (rc) return rc;
     }
     go.n = n_out;
@@ -836,7 +904,7 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
     it = m->plans.emplace(key, p).first;
   }
   if (n_out_host) *n_out_host = it->second.n_rows;
-  if (n_rules_host) *n_rules_host = it->second.n_rules;
+  if (n_rules_host) return plan_rules(m, it->second, s, n_rules_host);
   return D3D_OK;
 }
 
@@ -847,7 +915,7 @@ int d3d_deconv_prepare(d3d_meta *m, const int *in_size, const int *out_size, con
   const Plan *p = nullptr;
   int rc = get_deconv_plan(m, out_size, filt, stride, (hipStream_t)stream, &p);
   if (rc) return rc;
-  if (n_rules_host) *n_rules_host = p->n_rules;
+  if (n_rules_host) return plan_rules(m, *const_cast<Plan *>(p), (hipStream_t)stream, n_rules_host);
   return D3D_OK;
 }
 

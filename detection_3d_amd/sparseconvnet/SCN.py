@@ -30,10 +30,23 @@ def _scratch(device, nbytes):
 
 class ConvProfiler(object):
     """Optional per-launch timing of the sparse convolutions with HIP events recorded on the
-    stream the kernels are launched on (bench.py's roofline leg).  Off by default."""
+    stream the kernels are launched on (bench.py's roofline leg).  Off by default.
+
+    Rule counts live on the device and reading them costs a stream sync, so they are *learned* in an
+    untimed pass (`learn=True`, one entry per conv call of a scene, keyed by `scene_key`) and looked
+    up by call index while timing (`learn=False`), where only two event records per launch remain."""
 
     def __init__(self):
+        self.learn = False
+        self.scene_key = None
+        self.macs = {}      # scene_key -> [macs of call 0, 1, ...]
+        self._idx = 0
         self.records = []   # (key, flops, compulsory_bytes, start_event, end_event)
+
+    def start_scene(self, scene_key, learn):
+        self.scene_key, self.learn, self._idx = scene_key, learn, 0
+        if learn:
+            self.macs[scene_key] = []
 
     def begin(self):
         ev = torch.cuda.Event(enable_timing=True)
@@ -43,6 +56,11 @@ class ConvProfiler(object):
     def end(self, start, kind, fv, cin, cout, rows_in, rows_out, macs):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
+        if self.learn:
+            self.macs[self.scene_key].append(macs)
+            return
+        macs = self.macs[self.scene_key][self._idx]
+        self._idx += 1
         rules = macs / max(cin * cout, 1)
         # FLOPs = 2*rules*Cin*Cout; compulsory bytes = 4*(rows_in*Cin + rows_out*Cout) + 8*rules
         self.records.append(((kind, fv, cin, cout), 2.0 * macs, 4.0 * (rows_in * cin + rows_out * cout) + 8.0 * rules,
@@ -61,6 +79,9 @@ class ConvProfiler(object):
 
 
 PROFILER = None
+# The reference's *_updateOutput return the multiply-add count (rules*Cin*Cout).  Reading the rule
+# count back costs one stream synchronisation per layer, so it is only done when asked for.
+COUNT_MACS = False
 
 
 def set_profiler(p):
@@ -203,12 +224,12 @@ def SubmanifoldConvolution_updateOutput(spatial_size, filter_size, m, input_feat
     output_features.resize_(n, cout)
     macs = ctypes.c_double(0)
     prof = PROFILER
-    if prof is not None:   # make sure the rulebook build is not inside the timed launch
+    want = ctypes.byref(macs) if ((prof is not None and prof.learn) or COUNT_MACS) else None
+    if prof is not None:   # keep the rulebook build and the rule-count read-back out of the timed launch
         check(lib().d3d_subm_prepare(m._h, ints(size), ints(filt), stream_of(), None))
         t0 = prof.begin()
     check(lib().d3d_subm_conv_forward(m._h, ints(size), ints(filt), ptr(input_features), cin, ptr(packed),
-                                      cout, ptr(residual), ptr(output_features), stream_of(),
-                                      ctypes.byref(macs)))
+                                      cout, ptr(residual), ptr(output_features), stream_of(), want))
     if prof is not None:
         prof.end(t0, "subm", fv, cin, cout, n, n, macs.value)
     return macs.value
@@ -228,10 +249,11 @@ def Convolution_updateOutput(input_size, output_size, filter_size, filter_stride
     output_features.resize_(n_out.value, cout)
     macs = ctypes.c_double(0)
     prof = PROFILER
+    want = ctypes.byref(macs) if ((prof is not None and prof.learn) or COUNT_MACS) else None
     if prof is not None:
         t0 = prof.begin()
     check(lib().d3d_conv_forward(m._h, ints(isz), ints(osz), ints(filt), ints(st), ptr(input_features), cin,
-                                 ptr(packed), cout, ptr(output_features), stream_of(), ctypes.byref(macs)))
+                                 ptr(packed), cout, ptr(output_features), stream_of(), want))
     if prof is not None:
         prof.end(t0, "conv", fv, cin, cout, input_features.shape[0], n_out.value, macs.value)
     return macs.value
@@ -249,12 +271,13 @@ def Deconvolution_updateOutput(input_size, output_size, filter_size, filter_stri
     output_features.resize_(n, cout)
     macs = ctypes.c_double(0)
     prof = PROFILER
+    want = ctypes.byref(macs) if ((prof is not None and prof.learn) or COUNT_MACS) else None
     if prof is not None:
         check(lib().d3d_deconv_prepare(m._h, ints(isz), ints(osz), ints(filt), ints(st), stream_of(), None))
         t0 = prof.begin()
     check(lib().d3d_deconv_forward(m._h, ints(isz), ints(osz), ints(filt), ints(st), ptr(input_features),
                                    cin, ptr(packed), cout, ptr(residual), ptr(output_features), stream_of(),
-                                   ctypes.byref(macs)))
+                                   want))
     if prof is not None:
         prof.end(t0, "deconv", fv, cin, cout, input_features.shape[0], n, macs.value)
     return macs.value
