@@ -279,6 +279,32 @@ struct NmsBox {
   float radius;  // BEV circumscribed circle, for the exact far-apart early-out
   double area;
 };
+
+// Conservative separating-axis test of two quads (rectangles): true only if they are separated by
+// more than `margin` along one of the 4 edge directions -> they cannot touch, intersection area 0.
+__device__ __forceinline__ bool quads_separated(const float *a, const float *b, float margin) {
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const float *p = q ? b : a;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      float nx = p[2 * e + 3] - p[2 * e + 1], ny = -(p[2 * e + 2] - p[2 * e]);  // normal of edge e
+      const float len = sqrtf(nx * nx + ny * ny);
+      if (!(len > 0.f)) continue;
+      nx /= len;
+      ny /= len;
+      float amin = 1e30f, amax = -1e30f, bmin = 1e30f, bmax = -1e30f;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const float pa = a[2 * i] * nx + a[2 * i + 1] * ny, pb = b[2 * i] * nx + b[2 * i + 1] * ny;
+        amin = fminf(amin, pa); amax = fmaxf(amax, pa);
+        bmin = fminf(bmin, pb); bmax = fmaxf(bmax, pb);
+      }
+      if (amin > bmax + margin || bmin > amax + margin) return true;
+    }
+  }
+  return false;
+}
 __global__ void k_nms_prep(const float *__restrict__ boxes, int n, NmsBox *__restrict__ rec) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -295,8 +321,9 @@ __global__ void k_nms_prep(const float *__restrict__ boxes, int n, NmsBox *__res
 // 256 threads per 64 x 64 tile: wave w decides rows 16w..16w+15, lanes = candidate boxes j.
 // Two early-outs that cannot change the decision:
 //  * z intervals do not overlap  -> iou_z <= 0 (or NaN) -> gate `iou3d > 0` is false;
-//  * BEV circumscribed circles are disjoint (with a 0.1 % + 1e-4 margin, far above fp32 rounding of
-//    metre-sized boxes) -> no corner lies inside the other box and no edges cross -> area 0 -> gate false.
+//  * BEV circumscribed circles are disjoint, or the rectangles are separated along one of their edge
+//    normals (both with a margin of ~1e-3 of the box size, far above fp32 rounding of metre-sized
+//    boxes) -> no corner lies inside the other box and no edges cross -> area 0 -> gate false.
 __global__ __launch_bounds__(256) void k_nms_mask(const NmsBox *__restrict__ rec, int n, int ncb,
                                                   float thresh,
                                                   unsigned long long *__restrict__ mask) {
@@ -318,7 +345,8 @@ __global__ __launch_bounds__(256) void k_nms_mask(const NmsBox *__restrict__ rec
       const float overlap = fminf(cb.z1, rb.z1) - fmaxf(cb.z0, rb.z0);
       const float dx = cb.raw[0] - rb.raw[0], dy = cb.raw[1] - rb.raw[1];
       const float rr = (cb.radius + rb.radius) * 1.001f + 1e-4f;
-      if (overlap > 0.f && dx * dx + dy * dy <= rr * rr) {
+      if (overlap > 0.f && dx * dx + dy * dy <= rr * rr &&
+          !quads_separated(rb.q.p, cb.q.p, 1e-3f * (1.f + cb.radius + rb.radius))) {
         // gate = boxes_iou_3d(dets, dets)[i, j] > 0 (nms_cpu.py:35, spconv nms.h)
         float v = iou_eval(cb.q, cb.d0, cb.d1, rb.q, rb.d0, rb.d1, -1);
         bool same = true;
@@ -357,8 +385,11 @@ __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long *__re
     unsigned long long alive = ~__shfl(removed, c, 64);
     if (nrow < 64) alive &= (1ull << nrow) - 1ull;
     unsigned long long kept = 0;
+    const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
     for (int b = 0; b < nrow; b++) {
-      const unsigned long long d = __shfl(diag, b, 64);
+      // b is wave-uniform: v_readlane instead of a ds_bpermute round trip per dependent step
+      const unsigned long long d = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
+                                   (unsigned int)__builtin_amdgcn_readlane((int)dlo, b);
       if ((alive >> b) & 1ull) {
         kept |= 1ull << b;
         alive &= ~d;

@@ -61,13 +61,21 @@ struct Arena {
 
 static constexpr uint64_t kEmptyKey = ~uint64_t(0);
 
+// One 16-byte hash slot: a probe is a single aligned 16-B load.  Initialised to all ones
+// (key = empty, val = -1, first = UINT_MAX).  `first` = smallest index that touched the slot
+// while the grid was being built (first-occurrence numbering).
+struct __attribute__((aligned(16))) HashEntry {
+  uint64_t key;
+  int32_t val;
+  uint32_t first;
+};
+
 // Sparse grid of one spatial size: open-addressing hash (key -> site id) + site coordinates.
 struct Grid {
   int size[3] = {0, 0, 0};
   int n = 0;        // active sites
   int cap = 0;      // hash capacity (power of two)
-  uint64_t *keys = nullptr;
-  int32_t *vals = nullptr;
+  HashEntry *tab = nullptr;
   int32_t *loc = nullptr;  // [n,4] x,y,z,b
 };
 
@@ -140,22 +148,23 @@ __device__ __forceinline__ uint32_t hash_key(uint64_t k) {
   return (uint32_t)k;
 }
 // returns the slot holding `key` (inserting it if absent)
-__device__ __forceinline__ int hash_insert(uint64_t *keys, int cap, uint64_t key) {
+__device__ __forceinline__ int hash_insert(HashEntry *tab, int cap, uint64_t key) {
   uint32_t slot = hash_key(key) & (uint32_t)(cap - 1);
   while (true) {
-    unsigned long long prev = atomicCAS((unsigned long long *)&keys[slot],
+    unsigned long long prev = atomicCAS((unsigned long long *)&tab[slot].key,
                                         (unsigned long long)kEmptyKey, (unsigned long long)key);
     if (prev == kEmptyKey || prev == key) return (int)slot;
     slot = (slot + 1) & (uint32_t)(cap - 1);
   }
 }
-// returns the site id stored for `key`, or -1
-__device__ __forceinline__ int hash_find(const uint64_t *__restrict__ keys,
-                                         const int32_t *__restrict__ vals, int cap, uint64_t key) {
+// returns the site id stored for `key`, or -1 (one 16-B load per probed slot)
+__device__ __forceinline__ int hash_find(const HashEntry *__restrict__ tab, int cap, uint64_t key) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   uint32_t slot = hash_key(key) & (uint32_t)(cap - 1);
   while (true) {
-    uint64_t k = keys[slot];
-    if (k == key) return vals[slot];
+    const u32x4 e = *(const u32x4 *)&tab[slot];
+    const uint64_t k = ((uint64_t)e[1] << 32) | e[0];
+    if (k == key) return (int)e[2];
     if (k == kEmptyKey) return -1;
     slot = (slot + 1) & (uint32_t)(cap - 1);
   }

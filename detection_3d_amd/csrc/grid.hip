@@ -142,39 +142,39 @@ static inline dim3 grid1d(long n, int block = 256) { return dim3((unsigned)((n +
 // ------------------------------------------------------------------------------------------
 // a2. Input layer: hash insert + first-occurrence numbering (IOLayersRules.h:72-95).
 __global__ void k_insert_points(const int64_t *__restrict__ coords, int n, int ncols,
-                                uint64_t *keys, int32_t *first, int cap, int32_t *pslot) {
+                                HashEntry *tab, int cap, int32_t *pslot) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int64_t *c = coords + (size_t)i * ncols;
   int b = ncols == 4 ? (int)c[3] : 0;
-  int slot = hash_insert(keys, cap, pack_key(b, (int)c[0], (int)c[1], (int)c[2]));
-  atomicMin(&first[slot], i);
+  int slot = hash_insert(tab, cap, pack_key(b, (int)c[0], (int)c[1], (int)c[2]));
+  atomicMin(&tab[slot].first, (uint32_t)i);
   pslot[i] = slot;
 }
-__global__ void k_flag_first(const int32_t *__restrict__ pslot, const int32_t *__restrict__ first,
+__global__ void k_flag_first(const int32_t *__restrict__ pslot, const HashEntry *__restrict__ tab,
                              int n, int32_t *flag) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) flag[i] = (pslot[i] >= 0 && first[pslot[i]] == i) ? 1 : 0;
+  if (i < n) flag[i] = (pslot[i] >= 0 && tab[pslot[i]].first == (uint32_t)i) ? 1 : 0;
 }
 __global__ void k_assign_input_sites(const int64_t *__restrict__ coords, int n, int ncols,
                                      const int32_t *__restrict__ pslot,
                                      const int32_t *__restrict__ flag,
-                                     const int32_t *__restrict__ rank, int32_t *vals, int32_t *loc) {
+                                     const int32_t *__restrict__ rank, HashEntry *tab, int32_t *loc) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || !flag[i]) return;
   int id = rank[i];
-  vals[pslot[i]] = id;
+  tab[pslot[i]].val = id;
   const int64_t *c = coords + (size_t)i * ncols;
   loc[id * 4 + 0] = (int)c[0];
   loc[id * 4 + 1] = (int)c[1];
   loc[id * 4 + 2] = (int)c[2];
   loc[id * 4 + 3] = ncols == 4 ? (int)c[3] : 0;
 }
-__global__ void k_point_site(const int32_t *__restrict__ pslot, const int32_t *__restrict__ vals,
+__global__ void k_point_site(const int32_t *__restrict__ pslot, const HashEntry *__restrict__ tab,
                              int n, uint32_t *psite, int32_t *cnt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  int s = vals[pslot[i]];
+  int s = tab[pslot[i]].val;
   psite[i] = (uint32_t)s;
   atomicAdd(&cnt[s], 1);
 }
@@ -221,7 +221,7 @@ __device__ __forceinline__ bool conv_entry(const ConvGeom &g, const int32_t *p, 
   return true;
 }
 __global__ void k_conv_insert(const int32_t *__restrict__ loc, long n_entries, ConvGeom g,
-                              uint64_t *keys, int32_t *first, int cap, int32_t *eslot) {
+                              HashEntry *tab, int cap, int32_t *eslot) {
   long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_entries) return;
   int i = (int)(e / g.max_out), j = (int)(e % g.max_out);
@@ -231,13 +231,13 @@ __global__ void k_conv_insert(const int32_t *__restrict__ loc, long n_entries, C
     eslot[e] = -1;
     return;
   }
-  int slot = hash_insert(keys, cap, pack_key(p[3], o[0], o[1], o[2]));
-  atomicMin(&first[slot], (int)e);
+  int slot = hash_insert(tab, cap, pack_key(p[3], o[0], o[1], o[2]));
+  atomicMin(&tab[slot].first, (uint32_t)e);
   eslot[e] = slot;
 }
 __global__ void k_conv_assign(const int32_t *__restrict__ loc, long n_entries, ConvGeom g,
                               const int32_t *__restrict__ eslot, const int32_t *__restrict__ flag,
-                              const int32_t *__restrict__ rank, int32_t *vals, int32_t *loc_out) {
+                              const int32_t *__restrict__ rank, HashEntry *tab, int32_t *loc_out) {
   long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_entries || !flag[e]) return;
   int i = (int)(e / g.max_out), j = (int)(e % g.max_out);
@@ -245,14 +245,14 @@ __global__ void k_conv_assign(const int32_t *__restrict__ loc, long n_entries, C
   int o[3], off;
   conv_entry(g, p, j, o, &off);
   int id = rank[e];
-  vals[eslot[e]] = id;
+  tab[eslot[e]].val = id;
   loc_out[id * 4 + 0] = o[0];
   loc_out[id * 4 + 1] = o[1];
   loc_out[id * 4 + 2] = o[2];
   loc_out[id * 4 + 3] = p[3];
 }
 __global__ void k_conv_fill(const int32_t *__restrict__ loc, long n_entries, ConvGeom g, int K,
-                            const int32_t *__restrict__ eslot, const int32_t *__restrict__ vals,
+                            const int32_t *__restrict__ eslot, const HashEntry *__restrict__ tab,
                             int32_t *nbr_fwd, int32_t *nbr_dec) {
   long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_entries || eslot[e] < 0) return;
@@ -260,7 +260,7 @@ __global__ void k_conv_fill(const int32_t *__restrict__ loc, long n_entries, Con
   const int32_t *p = loc + (size_t)i * 4;
   int o[3], off;
   conv_entry(g, p, j, o, &off);
-  int oid = vals[eslot[e]];
+  int oid = tab[eslot[e]].val;
   nbr_fwd[(size_t)oid * K + off] = i;
   nbr_dec[(size_t)i * K + off] = oid;
 }
@@ -268,8 +268,7 @@ __global__ void k_conv_fill(const int32_t *__restrict__ loc, long n_entries, Con
 // a4. Submanifold neighbour probes (SubmanifoldConvolutionRules.h:13-45), one thread per output
 // site: the K probes are independent loads, the row's offset mask and the rule count come for free.
 __global__ __launch_bounds__(256) void k_subm_nbr(const int32_t *__restrict__ loc, int n, int fx, int fy,
-                                                  int fz, const uint64_t *__restrict__ keys,
-                                                  const int32_t *__restrict__ vals, int cap,
+                                                  int fz, const HashEntry *__restrict__ tab, int cap,
                                                   int32_t *__restrict__ nbr, uint32_t *__restrict__ mask,
                                                   unsigned long long *n_rules) {
   const int K = fx * fy * fz;
@@ -285,7 +284,7 @@ __global__ __launch_bounds__(256) void k_subm_nbr(const int32_t *__restrict__ lo
         for (int dz = 0; dz < fz; dz++, k++) {
           const int x = px + dx, y = py + dy, z = pz + dz;
           int v = -1;
-          if (x >= 0 && y >= 0 && z >= 0) v = hash_find(keys, vals, cap, pack_key(pb, x, y, z));
+          if (x >= 0 && y >= 0 && z >= 0) v = hash_find(tab, cap, pack_key(pb, x, y, z));
           nbr[(size_t)i * K + k] = v;
           m |= (v >= 0 ? 1u : 0u) << k;
         }
@@ -635,24 +634,20 @@ int d3d_input_layer_build(d3d_meta *m, const int64_t *coords, int n, int ncols, 
   Grid g;
   for (int d = 0; d < 3; d++) g.size[d] = size[d];
   g.cap = next_pow2(2L * n);
-  D3D_ALLOC(keys, uint64_t, A, g.cap);
-  D3D_ALLOC(vals, int32_t, A, g.cap);
+  D3D_ALLOC(tab, HashEntry, A, g.cap);
   D3D_ALLOC(loc, int32_t, A, (size_t)n * 4 + 4);
   D3D_ALLOC(in_off, int32_t, A, (size_t)n + 2);
   D3D_ALLOC(in_idx, int32_t, A, (size_t)n + 1);
-  g.keys = keys;
-  g.vals = vals;
+  g.tab = tab;
   g.loc = loc;
   m->in_n = n;
   m->in_mode = mode;
   m->in_off = in_off;
   m->in_idx = in_idx;
-  D3D_HIP_CHECK(hipMemsetAsync(keys, 0xFF, sizeof(uint64_t) * g.cap, s));
-  D3D_HIP_CHECK(hipMemsetAsync(vals, 0xFF, sizeof(int32_t) * g.cap, s));
+  D3D_HIP_CHECK(hipMemsetAsync(tab, 0xFF, sizeof(HashEntry) * g.cap, s));
   int n_active = 0;
   if (n > 0) {
     size_t mark = A.used;
-    D3D_ALLOC(first, int32_t, A, g.cap);
     D3D_ALLOC(pslot, int32_t, A, n);
     D3D_ALLOC(flag, int32_t, A, n);
     D3D_ALLOC(rank, int32_t, A, n);
@@ -661,19 +656,18 @@ int d3d_input_layer_build(d3d_meta *m, const int64_t *coords, int n, int ncols, 
     D3D_ALLOC(psite_sorted, uint32_t, A, n);
     D3D_ALLOC(iota, int32_t, A, n);
     D3D_ALLOC(cnt, int32_t, A, (size_t)n + 1);
-    D3D_HIP_CHECK(hipMemsetAsync(first, 0x7F, sizeof(int32_t) * g.cap, s));
-    hipLaunchKernelGGL(k_insert_points, grid1d(n), dim3(256), 0, s, coords, n, ncols, keys, first, g.cap, pslot);
-    hipLaunchKernelGGL(k_flag_first, grid1d(n), dim3(256), 0, s, pslot, first, n, flag);
+    hipLaunchKernelGGL(k_insert_points, grid1d(n), dim3(256), 0, s, coords, n, ncols, tab, g.cap, pslot);
+    hipLaunchKernelGGL(k_flag_first, grid1d(n), dim3(256), 0, s, pslot, tab, n, flag);
     int rc = scan_exclusive_i32(flag, rank, n, total, A, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_assign_input_sites, grid1d(n), dim3(256), 0, s, coords, n, ncols, pslot, flag, rank, vals, loc);
+    hipLaunchKernelGGL(k_assign_input_sites, grid1d(n), dim3(256), 0, s, coords, n, ncols, pslot, flag, rank, tab, loc);
     D3D_LAUNCH_CHECK();
     D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[0], total, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     D3D_HIP_CHECK(hipStreamSynchronize(s));
     n_active = (int)*(int32_t *)&m->host_words[0];
     // per-site point lists in input order: stable sort of point ids by site id
     D3D_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int32_t) * ((size_t)n_active + 1), s));
-    hipLaunchKernelGGL(k_point_site, grid1d(n), dim3(256), 0, s, pslot, vals, n, psite, cnt);
+    hipLaunchKernelGGL(k_point_site, grid1d(n), dim3(256), 0, s, pslot, tab, n, psite, cnt);
     hipLaunchKernelGGL(k_iota, grid1d(n), dim3(256), 0, s, iota, n);
     rc = scan_exclusive_i32(cnt, in_off, n_active + 1, nullptr, A, s);
     if (rc) return rc;
@@ -795,7 +789,7 @@ int d3d_subm_prepare(d3d_meta *m, const int *size, const int *filt, void *stream
       D3D_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), s));
       if (g->n)
         hipLaunchKernelGGL(k_subm_nbr, grid1d(g->n), dim3(256), 0, s, g->loc, g->n, filt[0], filt[1], filt[2],
-                           g->keys, g->vals, g->cap, nbr, mask, cnt);
+                           g->tab, g->cap, nbr, mask, cnt);
       D3D_LAUNCH_CHECK();
       int rc;
       {
@@ -847,15 +841,12 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
     Grid go;
     for (int d = 0; d < 3; d++) go.size[d] = out_size[d];
     go.cap = next_pow2(2L * n_entries);
-    D3D_ALLOC(keys, uint64_t, A, go.cap);
-    D3D_ALLOC(vals, int32_t, A, go.cap);
+    D3D_ALLOC(tab, HashEntry, A, go.cap);
     D3D_ALLOC(loc_out, int32_t, A, (size_t)n_entries * 4 + 4);
     D3D_ALLOC(nbr_dec, int32_t, A, (size_t)n_in * K + 1);
-    go.keys = keys;
-    go.vals = vals;
+    go.tab = tab;
     go.loc = loc_out;
-    D3D_HIP_CHECK(hipMemsetAsync(keys, 0xFF, sizeof(uint64_t) * go.cap, s));
-    D3D_HIP_CHECK(hipMemsetAsync(vals, 0xFF, sizeof(int32_t) * go.cap, s));
+    D3D_HIP_CHECK(hipMemsetAsync(tab, 0xFF, sizeof(HashEntry) * go.cap, s));
     D3D_HIP_CHECK(hipMemsetAsync(nbr_dec, 0xFF, sizeof(int32_t) * ((size_t)n_in * K + 1), s));
     Plan p;
     int n_out = 0;
@@ -863,29 +854,27 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
       // raw forward table staged at the far end of the arena (size known only after the scan:
       // bound it by n_entries rows)
       size_t raw_bytes = ((size_t)n_entries * K + 1) * sizeof(int32_t);
-      if (A.used + raw_bytes + 12 * (size_t)n_entries * sizeof(int32_t) + (size_t)go.cap * 4 + (1 << 20) > A.cap) {
+      if (A.used + raw_bytes + 12 * (size_t)n_entries * sizeof(int32_t) + (size_t)(1 << 20) > A.cap) {
         set_error("metadata arena exhausted while building a strided rulebook");
         return D3D_ERR_NOMEM;
       }
       int32_t *nbr_fwd = (int32_t *)(A.base + ((A.cap - raw_bytes) & ~size_t(255)));
       CapGuard guard(A, (A.cap - raw_bytes) & ~size_t(255));
       size_t mark = A.used;
-      D3D_ALLOC(first, int32_t, A, go.cap);
       D3D_ALLOC(eslot, int32_t, A, n_entries);
       D3D_ALLOC(flag, int32_t, A, n_entries);
       D3D_ALLOC(rank, int32_t, A, n_entries);
       D3D_ALLOC(total, int32_t, A, 1);
-      D3D_HIP_CHECK(hipMemsetAsync(first, 0x7F, sizeof(int32_t) * go.cap, s));
-      hipLaunchKernelGGL(k_conv_insert, grid1d(n_entries), dim3(256), 0, s, gi->loc, n_entries, geo, keys, first, go.cap, eslot);
-      hipLaunchKernelGGL(k_flag_first, grid1d(n_entries), dim3(256), 0, s, eslot, first, (int)n_entries, flag);
+      hipLaunchKernelGGL(k_conv_insert, grid1d(n_entries), dim3(256), 0, s, gi->loc, n_entries, geo, tab, go.cap, eslot);
+      hipLaunchKernelGGL(k_flag_first, grid1d(n_entries), dim3(256), 0, s, eslot, tab, (int)n_entries, flag);
       int rc = scan_exclusive_i32(flag, rank, (int)n_entries, total, A, s);
       if (rc) return rc;
-      hipLaunchKernelGGL(k_conv_assign, grid1d(n_entries), dim3(256), 0, s, gi->loc, n_entries, geo, eslot, flag, rank, vals, loc_out);
+      hipLaunchKernelGGL(k_conv_assign, grid1d(n_entries), dim3(256), 0, s, gi->loc, n_entries, geo, eslot, flag, rank, tab, loc_out);
       D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[0], total, sizeof(int32_t), hipMemcpyDeviceToHost, s));
       D3D_HIP_CHECK(hipStreamSynchronize(s));
       n_out = (int)*(int32_t *)&m->host_words[0];
       D3D_HIP_CHECK(hipMemsetAsync(nbr_fwd, 0xFF, sizeof(int32_t) * ((size_t)n_out * K + 1), s));
-      hipLaunchKernelGGL(k_conv_fill, grid1d(n_entries), dim3(256), 0, s, gi->loc, n_entries, geo, K, eslot, vals, nbr_fwd, nbr_dec);
+      hipLaunchKernelGGL(k_conv_fill, grid1d(n_entries), dim3(256), 0, s, gi->loc, n_entries, geo, K, eslot, tab, nbr_fwd, nbr_dec);
       D3D_LAUNCH_CHECK();
       A.used = mark;
       rc = finalize_plan(m, nbr_fwd, n_out, K, p, s, nullptr);

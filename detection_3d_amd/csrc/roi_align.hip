@@ -112,8 +112,7 @@ __global__ __launch_bounds__(256) void k_roi_dense(const float *__restrict__ inp
 // so that the [K, C, ph, pw, pz] output is written in contiguous runs.
 static constexpr int kRoiCch = 64;
 __global__ __launch_bounds__(256) void k_roi_sparse(
-    const uint64_t *__restrict__ keys, const int32_t *__restrict__ vals, int cap,
-    const float *__restrict__ feats, int C, int H, int W, int Z, const float *__restrict__ rois,
+    const HashEntry *__restrict__ tab, int cap, const float *__restrict__ feats, int C, int H, int W, int Z, const float *__restrict__ rois,
     float spatial_scale, int PH, int PW, int PZ, int sampling_ratio, float *__restrict__ out) {
   extern __shared__ float tile[];  // [kRoiCch][NB + 1]
   const int n = blockIdx.x, cc = blockIdx.y;
@@ -141,7 +140,7 @@ __global__ __launch_bounds__(256) void k_roi_sparse(
           const int zb = corner >> 2, yb = (corner >> 1) & 1, xb = corner & 1;
           wgt = (yb ? t.ly : t.hy) * (xb ? t.lx : t.hx) * (zb ? t.lz : t.hz);
           // dense index [y][x][z]: y runs over the tensor's 1st spatial axis, x over the 2nd
-          row = hash_find(keys, vals, cap, pack_key(g.b, yb ? t.yh : t.yl, xb ? t.xh : t.xl, zb ? t.zh : t.zl));
+          row = hash_find(tab, cap, pack_key(g.b, yb ? t.yh : t.yl, xb ? t.xh : t.xl, zb ? t.zh : t.zl));
         }
       }
       // ---- lanes = channels ----
@@ -206,7 +205,7 @@ int d3d_roi_align_rotated_3d_sparse_forward(d3d_meta *m, const int *size, const 
   const int NB = ph * pw * pz;
   size_t lds = (size_t)kRoiCch * (NB + 1) * sizeof(float);
   D3D_REQUIRE(lds <= 64 * 1024, "roi_align_sparse: pooled volume %d too large", NB);
-  hipLaunchKernelGGL(k_roi_sparse, dim3(K, (C + kRoiCch - 1) / kRoiCch), dim3(256), lds, s, g.keys, g.vals, g.cap, feats, C, crop[0], crop[1], crop[2], rois, spatial_scale, ph, pw, pz, sampling_ratio, out);
+  hipLaunchKernelGGL(k_roi_sparse, dim3(K, (C + kRoiCch - 1) / kRoiCch), dim3(256), lds, s, g.tab, g.cap, feats, C, crop[0], crop[1], crop[2], rois, spatial_scale, ph, pw, pz, sampling_ratio, out);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }
