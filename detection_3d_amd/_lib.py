@@ -44,6 +44,22 @@ _SIGS = {
                                         ctypes.c_int, vp, vp, ctypes.POINTER(ctypes.c_double)]),
     "d3d_deconv_forward": (ctypes.c_int, [vp, c_int_p, c_int_p, c_int_p, c_int_p, vp, ctypes.c_int, vp,
                                           ctypes.c_int, vp, vp, vp, ctypes.POINTER(ctypes.c_double)]),
+    "d3d_pack_conv_weight_transposed": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                       vp, vp]),
+    "d3d_subm_conv_backward": (ctypes.c_int, [vp, c_int_p, c_int_p, vp, ctypes.c_int, vp, ctypes.c_int, vp, vp,
+                                              vp, vp]),
+    "d3d_conv_backward": (ctypes.c_int, [vp, c_int_p, c_int_p, c_int_p, c_int_p, vp, ctypes.c_int, vp,
+                                         ctypes.c_int, vp, vp, vp, vp]),
+    "d3d_deconv_backward": (ctypes.c_int, [vp, c_int_p, c_int_p, c_int_p, c_int_p, vp, ctypes.c_int, vp,
+                                           ctypes.c_int, vp, vp, vp, vp]),
+    "d3d_bn_backward": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp,
+                                       ctypes.c_float, vp, ctypes.c_size_t, vp]),
+    "d3d_bn_backward_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "d3d_input_layer_backward": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, vp]),
+    "d3d_roi_align_rotated_3d_sparse_backward": (ctypes.c_int, [vp, c_int_p, vp, ctypes.c_int, c_int_p, vp,
+                                                                ctypes.c_int, ctypes.c_float, ctypes.c_int,
+                                                                ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                                vp, vp]),
     "d3d_bn_forward": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp,
                                       ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_float, vp,
                                       ctypes.c_size_t, vp]),

@@ -1,0 +1,371 @@
+// a7. Backward of the sparse ops (training rows): convolution dInput / dWeight, BatchNorm,
+// input layer, sparse RoIAlign.  Reference: SCN/CUDA/Convolution.cu:249-442 (fused dI + dW with
+// atomicAdd on dW), SCN/CPU/BatchNormalization.cpp:62-107, SCN/CPU/IOLayers.cpp:30-47,
+// maskrcnn_benchmark/csrc/cuda/ROIAlignRotated3D_cuda.cu:182-354.
+//
+// dInput needs no new kernel: it is the forward gather-GEMM on the transposed rulebook with W^T
+//   submanifold: nbr[i][k] = j  <=>  nbr[j][K-1-k] = i  -> same plan, offsets flipped;
+//   strided conv: the deconvolution plan;  deconvolution: the convolution plan.
+// dWeight[k] = sum over rules of offset k of in[r_in]^T (x) dOut[r_out]: MFMA with the rule index
+// as the contraction dimension, partial tiles added with fp32 atomics (as the reference does).
+#include <algorithm>
+
+#include "d3d_internal.h"
+
+namespace d3d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// packed_t[k'][g][ci][j] = w[k][ci][4g+j]  (a conv weight with Cin' = cout, Cout' = cin), k' = flip ? K-1-k : k
+__global__ void k_pack_weight_t(const float *__restrict__ w, int fv, int cin, int cout, int cp, int flip,
+                                float *__restrict__ packed) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)fv * cp * cin;
+  if (t >= total) return;
+  int j = (int)(t & 3);
+  long u = t >> 2;
+  int ci = (int)(u % cin);
+  u /= cin;
+  int g = (int)(u % (cp / 4));
+  int kp = (int)(u / (cp / 4));
+  int k = flip ? fv - 1 - kp : kp;
+  int co = 4 * g + j;
+  packed[t] = co < cout ? w[((size_t)k * cin + ci) * cout + co] : 0.f;
+}
+
+static constexpr int kDwBlocksPerWg = 64;
+
+// One workgroup: offset k = blockIdx.y, a run of row blocks, a group of <= 16 output tiles (32x32)
+template <int CP, int COUT>
+__global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ in, int cin,
+                                                 const float *__restrict__ d_out,
+                                                 const int32_t *__restrict__ nbrT, int npos,
+                                                 const int32_t *__restrict__ rows,
+                                                 const uint32_t *__restrict__ blkmask, int n_blk,
+                                                 float *__restrict__ dW) {
+  constexpr int NTI = CP / 32, NTJ = COUT / 32, T = NTI * NTJ;
+  constexpr int TPG = T < 16 ? T : 16;             // tiles per group (grid.z)
+  constexpr int TPW = (TPG + 3) / 4;               // tiles per wave
+  __shared__ __attribute__((aligned(16))) float As[32 * CP];
+  __shared__ __attribute__((aligned(16))) float Bs[32 * COUT];
+  const int k = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = lane & 31, kk = lane >> 5;
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; t++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+  const int b0 = blockIdx.x * kDwBlocksPerWg, b1 = min(n_blk, b0 + kDwBlocksPerWg);
+  const bool vec = (cin % 4) == 0;
+  bool any = false;
+  for (int b = b0; b < b1; b++) {
+    if (!((blkmask[b] >> k) & 1u)) continue;  // wave-uniform
+    any = true;
+    __syncthreads();
+    // gather the 32 input rows of (offset k, block b) and the 32 dOut rows
+    for (int e = threadIdx.x; e < 32 * (CP / 4); e += 256) {
+      const int row = e / (CP / 4), c4 = e % (CP / 4);
+      const int s = nbrT[(size_t)k * npos + b * 32 + row];
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (s >= 0) {
+        const float *p = in + (size_t)s * cin + c4 * 4;
+        if (vec && c4 * 4 + 3 < cin) {
+          v = *(const f32x4 *)p;
+        } else {
+          if (c4 * 4 + 0 < cin) v[0] = p[0];
+          if (c4 * 4 + 1 < cin) v[1] = p[1];
+          if (c4 * 4 + 2 < cin) v[2] = p[2];
+          if (c4 * 4 + 3 < cin) v[3] = p[3];
+        }
+      }
+      *(f32x4 *)(As + row * CP + c4 * 4) = v;
+    }
+    for (int e = threadIdx.x; e < 32 * (COUT / 4); e += 256) {
+      const int row = e / (COUT / 4), c4 = e % (COUT / 4);
+      const int o = rows[b * 32 + row];
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (o >= 0) v = *(const f32x4 *)(d_out + (size_t)o * COUT + c4 * 4);
+      *(f32x4 *)(Bs + row * COUT + c4 * 4) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TPW; t++) {
+      const int tile = blockIdx.z * TPG + wave * TPW + t;
+      if (wave * TPW + t >= TPG || tile >= T) continue;
+      const int ti = tile / NTJ, tj = tile % NTJ;
+#pragma unroll
+      for (int s = 0; s < 16; s++) {
+        const float a = As[(2 * s + kk) * CP + ti * 32 + i];
+        const float bb = Bs[(2 * s + kk) * COUT + tj * 32 + i];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  if (!any) return;
+#pragma unroll
+  for (int t = 0; t < TPW; t++) {
+    const int tile = blockIdx.z * TPG + wave * TPW + t;
+    if (wave * TPW + t >= TPG || tile >= T) continue;
+    const int ti = tile / NTJ, tj = tile % NTJ;
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+      const int ci = ti * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kk;
+      const int co = tj * 32 + i;
+      if (ci < cin) atomicAdd(dW + ((size_t)k * cin + ci) * COUT + co, acc[t][reg]);
+    }
+  }
+}
+
+template <int CP, int COUT>
+static int launch_dw_t(const Plan &p, const float *in, int cin, const float *d_out, float *dW, hipStream_t s) {
+  constexpr int T = (CP / 32) * (COUT / 32);
+  constexpr int TPG = T < 16 ? T : 16;
+  dim3 grid((p.n_blk + kDwBlocksPerWg - 1) / kDwBlocksPerWg, p.K, (T + TPG - 1) / TPG);
+  hipLaunchKernelGGL((k_conv_dw<CP, COUT>), grid, dim3(256), 0, s, in, cin, d_out, p.nbrT, p.n_blk * 32, p.rows,
+                     p.blkmask, p.n_blk, dW);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+template <int CP>
+static int launch_dw_c(const Plan &p, const float *in, int cin, const float *d_out, int cout, float *dW, hipStream_t s) {
+  switch (cout) {
+    case 32: return launch_dw_t<CP, 32>(p, in, cin, d_out, dW, s);
+    case 64: return launch_dw_t<CP, 64>(p, in, cin, d_out, dW, s);
+    case 128: return launch_dw_t<CP, 128>(p, in, cin, d_out, dW, s);
+    case 256: return launch_dw_t<CP, 256>(p, in, cin, d_out, dW, s);
+  }
+  set_error("conv backward: Cout=%d not supported", cout);
+  return D3D_ERR_UNSUPPORTED;
+}
+// dW[K, cin, cout] += ...   (dW pre-zeroed by the caller, like the reference's d_weight)
+static int launch_dw(const Plan &p, const float *in, int cin, const float *d_out, int cout, float *dW, hipStream_t s) {
+  if (p.n_rows == 0) return D3D_OK;
+  D3D_REQUIRE(in && d_out && dW, "conv backward: null pointer");
+  if (cin <= 32) return launch_dw_c<32>(p, in, cin, d_out, cout, dW, s);
+  if (cin <= 64) return launch_dw_c<64>(p, in, cin, d_out, cout, dW, s);
+  if (cin <= 128) return launch_dw_c<128>(p, in, cin, d_out, cout, dW, s);
+  if (cin <= 256) return launch_dw_c<256>(p, in, cin, d_out, cout, dW, s);
+  set_error("conv backward: Cin=%d not supported", cin);
+  return D3D_ERR_UNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm backward (CPU/BatchNormalization.cpp:62-107): partial sums of d' = dOut * relu' and
+// (x - mean) d', fixed-order reduction, then the elementwise pass.
+static constexpr int kBnBwdBlocks = 512;
+__global__ __launch_bounds__(256) void k_bn_bwd_partial(const float *__restrict__ x, const float *__restrict__ y,
+                                                        const float *__restrict__ dy, int rows, int C,
+                                                        const float *__restrict__ mean, float leak,
+                                                        double *__restrict__ partial) {
+  extern __shared__ double red[];
+  const int tid = threadIdx.x;
+  const int lpr = C < 256 ? C : 256, row_lanes = 256 / lpr;
+  const int rl = tid / lpr, cl = tid % lpr;
+  const int per = (rows + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
+  for (int c = cl; c < C; c += lpr) {
+    double s = 0, dp = 0;
+    const float mu = mean[c];
+    for (int r = r0 + rl; r < r1; r += row_lanes) {
+      const size_t i = (size_t)r * C + c;
+      const float d = dy[i] * ((y[i] > 0) ? 1.f : leak);
+      s += (double)d;
+      dp += (double)((x[i] - mu) * d);
+    }
+    red[tid * 2] = s;
+    red[tid * 2 + 1] = dp;
+    __syncthreads();
+    if (rl == 0) {
+      for (int j = 1; j < row_lanes; j++) {
+        s += red[(j * lpr + cl) * 2];
+        dp += red[(j * lpr + cl) * 2 + 1];
+      }
+      partial[(size_t)blockIdx.x * 2 * C + c] = s;
+      partial[(size_t)blockIdx.x * 2 * C + C + c] = dp;
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void k_bn_bwd_finish(const double *__restrict__ partial, int nblk, int rows,
+                                                       int C, const float *__restrict__ invstd,
+                                                       float *grad_mean, float *kcoef, float *d_weight,
+                                                       float *d_bias) {
+  __shared__ double red[256][2];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s = 0, dp = 0;
+  if (c < C)
+    for (int b = sl; b < nblk; b += 8) {
+      s += partial[(size_t)b * 2 * C + c];
+      dp += partial[(size_t)b * 2 * C + C + c];
+    }
+  red[threadIdx.x][0] = s;
+  red[threadIdx.x][1] = dp;
+  __syncthreads();
+  if (sl != 0 || c >= C) return;
+  for (int j = 1; j < 8; j++) {
+    s += red[j * 32 + cl][0];
+    dp += red[j * 32 + cl][1];
+  }
+  const float is = invstd[c];
+  if (d_bias) d_bias[c] = (float)s;
+  if (d_weight) d_weight[c] = (float)dp * is;
+  grad_mean[c] = (float)(s / rows);
+  kcoef[c] = (float)dp * is * is / rows;
+}
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ x, const float *__restrict__ y,
+                                                      const float *__restrict__ dy, float *__restrict__ dx,
+                                                      size_t total, int C, const float *__restrict__ mean,
+                                                      const float *__restrict__ invstd,
+                                                      const float *__restrict__ weight,
+                                                      const float *__restrict__ grad_mean,
+                                                      const float *__restrict__ kcoef, float leak) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const float d = dy[i] * ((y[i] > 0) ? 1.f : leak);
+  dx[i] = (d - grad_mean[c] - (x[i] - mean[c]) * kcoef[c]) * invstd[c] * (weight ? weight[c] : 1.f);
+}
+
+// Input layer backward (CPU/IOLayers.cpp:30-47): every point receives multiplier * d_out[site].
+__global__ void k_input_backward(const float *__restrict__ d_out, int planes, const int32_t *__restrict__ off,
+                                 const int32_t *__restrict__ idx, int n_active, int average,
+                                 float *__restrict__ d_in) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)n_active * planes) return;
+  const int row = (int)(t / planes), c = (int)(t % planes);
+  const int b = off[row], e = off[row + 1];
+  const float mult = (average && e > b) ? (float)1 / (e - b) : (float)1;
+  const float g = mult * d_out[t];
+  for (int j = b; j < e; j++) d_in[(size_t)idx[j] * planes + c] = g;
+}
+
+}  // namespace d3d
+
+using namespace d3d;
+
+extern "C" {
+
+int d3d_pack_conv_weight_transposed(const float *w, int fv, int cin, int cout, int flip, float *packed,
+                                    void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  size_t n = d3d_packed_weight_floats(fv, cout, cin);
+  D3D_REQUIRE(w && packed && n > 0, "pack_conv_weight_transposed: bad arguments (Cin=%d Cout=%d)", cin, cout);
+  int cp = (int)(n / ((size_t)fv * cin));
+  long total = (long)n;
+  hipLaunchKernelGGL(k_pack_weight_t, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, fv, cin, cout, cp,
+                     flip, packed);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+// d_in [rows_in, cin] (overwritten), d_weight [fv, cin, cout] (accumulated into; pre-zero it)
+int d3d_subm_conv_backward(d3d_meta *m, const int *size, const int *filt, const float *in, int cin,
+                           const float *packed_wt_flipped, int cout, const float *d_out, float *d_in,
+                           float *d_weight, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(m && size && filt, "null argument");
+  for (int d = 0; d < 3; d++) D3D_REQUIRE(filt[d] % 2 == 1, "submanifold backward needs odd filter sizes");
+  int rc = d3d_subm_prepare(m, size, filt, stream, nullptr);
+  if (rc) return rc;
+  const Plan *p = find_plan(m, 0, size, filt, nullptr);
+  if (d_in) {
+    rc = launch_conv(m, *p, d_out, cout, packed_wt_flipped, cin, nullptr, d_in, s);
+    if (rc) return rc;
+  }
+  if (d_weight) return launch_dw(*p, in, cin, d_out, cout, d_weight, s);
+  return D3D_OK;
+}
+
+int d3d_conv_backward(d3d_meta *m, const int *in_size, const int *out_size, const int *filt,
+                      const int *stride, const float *in, int cin, const float *packed_wt, int cout,
+                      const float *d_out, float *d_in, float *d_weight, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(m && in_size && out_size && filt && stride, "null argument");
+  const Plan *fwd = find_plan(m, 1, in_size, filt, stride);
+  if (!fwd) {
+    set_error("conv backward: forward rulebook not built");
+    return D3D_ERR_STATE;
+  }
+  if (d_in) {
+    const Plan *dec = nullptr;
+    int rc = get_deconv_plan(m, in_size, filt, stride, s, &dec);
+    if (rc) return rc;
+    rc = launch_conv(m, *dec, d_out, cout, packed_wt, cin, nullptr, d_in, s);
+    if (rc) return rc;
+  }
+  if (d_weight) return launch_dw(*fwd, in, cin, d_out, cout, d_weight, s);
+  return D3D_OK;
+}
+
+int d3d_deconv_backward(d3d_meta *m, const int *in_size, const int *out_size, const int *filt,
+                        const int *stride, const float *in, int cin, const float *packed_wt, int cout,
+                        const float *d_out, float *d_in, float *d_weight, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(m && in_size && out_size && filt && stride, "null argument");
+  const Plan *conv = find_plan(m, 1, out_size, filt, stride);  // fine -> coarse rulebook
+  if (!conv) {
+    set_error("deconv backward: strided rulebook not built");
+    return D3D_ERR_STATE;
+  }
+  if (d_in) {
+    int rc = launch_conv(m, *conv, d_out, cout, packed_wt, cin, nullptr, d_in, s);
+    if (rc) return rc;
+  }
+  if (d_weight) {
+    const Plan *dec = nullptr;
+    int rc = get_deconv_plan(m, out_size, filt, stride, s, &dec);
+    if (rc) return rc;
+    return launch_dw(*dec, in, cin, d_out, cout, d_weight, s);
+  }
+  return D3D_OK;
+}
+
+size_t d3d_bn_backward_scratch_bytes(int planes) {
+  return (size_t)kBnBwdBlocks * 2 * planes * sizeof(double) + 2 * (size_t)planes * sizeof(float) + 512;
+}
+
+int d3d_bn_backward(const float *in, const float *out, const float *d_out, float *d_in, int rows, int planes,
+                    const float *save_mean, const float *save_invstd, const float *weight, float *d_weight,
+                    float *d_bias, float leakiness, void *scratch, size_t scratch_bytes, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(planes > 0 && rows >= 0 && save_mean && save_invstd, "bn_backward: bad arguments");
+  if (rows == 0) return D3D_OK;
+  D3D_REQUIRE(in && out && d_out && d_in, "bn_backward: null features");
+  D3D_REQUIRE(planes >= 256 ? (planes % 256 == 0) : (256 % planes == 0), "bn_backward: planes=%d unsupported", planes);
+  D3D_REQUIRE(scratch && scratch_bytes >= d3d_bn_backward_scratch_bytes(planes), "bn_backward: scratch too small");
+  int nblk = kBnBwdBlocks;
+  if (rows < nblk * 64) nblk = std::max(1, (rows + 63) / 64);
+  double *partial = (double *)scratch;
+  float *grad_mean = (float *)((char *)scratch + (size_t)kBnBwdBlocks * 2 * planes * sizeof(double));
+  float *kcoef = grad_mean + planes;
+  hipLaunchKernelGGL(k_bn_bwd_partial, dim3(nblk), dim3(256), 256 * 2 * sizeof(double), s, in, out, d_out, rows, planes,
+                     save_mean, leakiness, partial);
+  hipLaunchKernelGGL(k_bn_bwd_finish, dim3((planes + 31) / 32), dim3(256), 0, s, partial, nblk, rows, planes,
+                     save_invstd, grad_mean, kcoef, d_weight, d_bias);
+  size_t total = (size_t)rows * planes;
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, d_out, d_in, total,
+                     planes, save_mean, save_invstd, weight, grad_mean, kcoef, leakiness);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+int d3d_input_layer_backward(d3d_meta *m, const float *d_out, int planes, float *d_in, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(m && planes > 0, "bad arguments");
+  if (!m->in_off) {
+    set_error("input layer backward before build");
+    return D3D_ERR_STATE;
+  }
+  if (m->in_active == 0) return D3D_OK;
+  D3D_REQUIRE(d_out && d_in, "null gradient pointer");
+  long total = (long)m->in_active * planes;
+  hipLaunchKernelGGL(k_input_backward, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_out, planes,
+                     m->in_off, m->in_idx, m->in_active, m->in_mode == 4 ? 1 : 0, d_in);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+}  // extern "C"

@@ -169,6 +169,56 @@ __global__ __launch_bounds__(256) void k_roi_sparse(
   for (int idx = threadIdx.x; idx < nch * NB; idx += 256) o[idx] = tile[(idx / NB) * LD + idx % NB];
 }
 
+// Backward of the sparse variant: the dense gradient of RoIAlignRotated3DBackwardFeature (:238-354)
+// restricted to the active sites (what SparseToDense_updateGradInput would gather back).  Keeps the
+// backward's own bound test `z > zsize` (:190).  fp32 atomics, like the reference.
+__global__ __launch_bounds__(256) void k_roi_sparse_bwd(
+    const HashEntry *__restrict__ tab, int cap, int C, int H, int W, int Z, const float *__restrict__ rois,
+    float spatial_scale, int PH, int PW, int PZ, int sampling_ratio, const float *__restrict__ top_diff,
+    float *__restrict__ d_feats) {
+  extern __shared__ float tile[];  // [kRoiCch][NB + 1]
+  const int n = blockIdx.x, cc = blockIdx.y;
+  const int NB = PH * PW * PZ, LD = NB + 1;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nch = min(kRoiCch, C - cc * kRoiCch);
+  const float *g0 = top_diff + ((size_t)n * C + (size_t)cc * kRoiCch) * NB;
+  for (int idx = threadIdx.x; idx < nch * NB; idx += 256) tile[(idx / NB) * LD + idx % NB] = g0[idx];
+  __syncthreads();
+  const RoiGeom g = roi_geom(rois + (size_t)n * 8, spatial_scale, PH, PW, PZ, sampling_ratio);
+  const int NS = g.gh * g.gw * g.gz;
+  const float count = (float)NS;
+  const int c = cc * kRoiCch + lane;
+  const bool cok = c < C;
+  for (int bin = wave; bin < NB; bin += 4) {
+    const int pz = bin % PZ, pw = (bin / PZ) % PW, ph = bin / (PZ * PW);
+    const float top = cok ? tile[lane * LD + bin] : 0.f;
+    for (int s0 = 0; s0 < NS; s0 += 8) {
+      const int s = s0 + (lane >> 3), corner = lane & 7;
+      int row = -1;
+      float wgt = 0.f;
+      if (s < NS) {
+        const int iz = s % g.gz, ix = (s / g.gz) % g.gw, iy = s / (g.gz * g.gw);
+        float y, x, z;
+        sample_pos(g, ph, pw, pz, iy, ix, iz, y, x, z);
+        Tri t;
+        if (!(z > Z) && tri_setup(y, x, z, H, W, Z, t)) {
+          const int zb = corner >> 2, yb = (corner >> 1) & 1, xb = corner & 1;
+          wgt = (yb ? t.ly : t.hy) * (xb ? t.lx : t.hx) * (zb ? t.lz : t.hz);
+          row = hash_find(tab, cap, pack_key(g.b, yb ? t.yh : t.yl, xb ? t.xh : t.xl, zb ? t.zh : t.zl));
+        }
+      }
+      unsigned long long m = __ballot(row >= 0);
+      while (m) {
+        const int src = __builtin_ctzll(m);
+        m &= m - 1;
+        const int rr = __shfl(row, src, 64);
+        const float ww = __shfl(wgt, src, 64);
+        if (cok) atomicAdd(d_feats + (size_t)rr * C + c, top * ww / count);
+      }
+    }
+  }
+}
+
 }  // namespace d3d
 
 using namespace d3d;
@@ -206,6 +256,30 @@ int d3d_roi_align_rotated_3d_sparse_forward(d3d_meta *m, const int *size, const 
   size_t lds = (size_t)kRoiCch * (NB + 1) * sizeof(float);
   D3D_REQUIRE(lds <= 64 * 1024, "roi_align_sparse: pooled volume %d too large", NB);
   hipLaunchKernelGGL(k_roi_sparse, dim3(K, (C + kRoiCch - 1) / kRoiCch), dim3(256), lds, s, g.tab, g.cap, feats, C, crop[0], crop[1], crop[2], rois, spatial_scale, ph, pw, pz, sampling_ratio, out);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+// d_feats [n_active, C] is accumulated into (zero it first)
+int d3d_roi_align_rotated_3d_sparse_backward(d3d_meta *m, const int *size, const float *top_diff, int C,
+                                             const int *crop, const float *rois, int K, float spatial_scale,
+                                             int ph, int pw, int pz, int sampling_ratio, float *d_feats,
+                                             void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(m && size && crop && C > 0 && K >= 0 && ph > 0 && pw > 0 && pz > 0, "roi_align_sparse_backward: bad arguments");
+  auto it = m->grids.find(Size3{size[0], size[1], size[2]});
+  if (it == m->grids.end()) {
+    set_error("roi_align_sparse_backward: no grid of spatial size [%d,%d,%d]", size[0], size[1], size[2]);
+    return D3D_ERR_STATE;
+  }
+  if (K == 0) return D3D_OK;
+  D3D_REQUIRE(top_diff && rois && d_feats, "roi_align_sparse_backward: null pointer");
+  const Grid &g = it->second;
+  const int NB = ph * pw * pz;
+  size_t lds = (size_t)kRoiCch * (NB + 1) * sizeof(float);
+  D3D_REQUIRE(lds <= 64 * 1024, "roi_align_sparse_backward: pooled volume %d too large", NB);
+  hipLaunchKernelGGL(k_roi_sparse_bwd, dim3(K, (C + kRoiCch - 1) / kRoiCch), dim3(256), lds, s, g.tab, g.cap, C,
+                     crop[0], crop[1], crop[2], rois, spatial_scale, ph, pw, pz, sampling_ratio, top_diff, d_feats);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }

@@ -164,9 +164,9 @@ class Pooler(nn.Module):
         dif = torch.abs(torch.tensor(self.scales, device=boxes.device)[None, :] - rate[:, None])
         return torch.argmin(dif, 1)
 
-    @torch.no_grad()
     def forward(self, x, boxes_pixels):
-        rois = convert_to_roi_format(boxes_pixels)
+        with torch.no_grad():
+            rois = convert_to_roi_format(boxes_pixels)
         ph, pw, pz = self.output_size
         if len(self.scales) == 1:
             return roi_align_rotated_3d_sparse(x[0], rois, self.scales[0], ph, pw, pz, self.sampling_ratio)

@@ -21,23 +21,46 @@ def roi_align_rotated_3d_forward(input, rois, spatial_scale, pooled_height, pool
     return out
 
 
+class _RoiSparseFn(torch.autograd.Function):
+    """forward: d3d_roi_align_rotated_3d_sparse_forward; backward: the dense backward of
+    layers/roi_align_rotated_3d.py:29-51 restricted to the active sites (scatter-add into feature rows)."""
+
+    @staticmethod
+    def forward(ctx, feats, rois, metadata, spatial_size, crop, spatial_scale, ph, pw, pz, sampling_ratio):
+        f = feats.contiguous()
+        K, C = rois.shape[0], f.shape[1]
+        out = torch.empty((K, C, ph, pw, pz), dtype=torch.float32, device=f.device)
+        check(lib().d3d_roi_align_rotated_3d_sparse_forward(
+            metadata._h, ints(spatial_size), ptr(f), C, ints(crop), ptr(rois), K, float(spatial_scale), ph, pw, pz,
+            int(sampling_ratio), ptr(out), stream_of()))
+        ctx.save_for_backward(rois)
+        ctx.args = (metadata, spatial_size, crop, spatial_scale, ph, pw, pz, sampling_ratio, f.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        (rois,) = ctx.saved_tensors
+        metadata, spatial_size, crop, spatial_scale, ph, pw, pz, sampling_ratio, shape = ctx.args
+        g = grad.contiguous()
+        d_feats = torch.zeros(shape, dtype=torch.float32, device=g.device)
+        check(lib().d3d_roi_align_rotated_3d_sparse_backward(
+            metadata._h, ints(spatial_size), ptr(g), shape[1], ints(crop), ptr(rois), rois.shape[0],
+            float(spatial_scale), ph, pw, pz, int(sampling_ratio), ptr(d_feats), stream_of()))
+        return d_feats, None, None, None, None, None, None, None, None, None
+
+
 def roi_align_rotated_3d_sparse(feat_s3d, rois, spatial_scale, pooled_height, pooled_width, pooled_zsize,
                                 sampling_ratio, crop=None):
     """Equals roi_align_rotated_3d_forward(sparse_3d_to_dense_2d(feat_s3d), ...)
     (sparseconvnet/tools_3d_2d.py:7-48 crops the dense map to the occupied extent = `crop`)."""
-    f = feat_s3d.features.contiguous()
     r = rois.detach().to(torch.float32).contiguous()
-    require_gpu(f, r)
+    require_gpu(feat_s3d.features, r)
     if crop is None:
         loc = feat_s3d.get_spatial_locations()
         crop = (loc[:, :3].max(0)[0] + 1).tolist()
-    K, C = r.shape[0], f.shape[1]
-    out = torch.empty((K, C, pooled_height, pooled_width, pooled_zsize), dtype=torch.float32, device=f.device)
-    check(lib().d3d_roi_align_rotated_3d_sparse_forward(
-        feat_s3d.metadata._h, ints(feat_s3d.spatial_size.tolist()), ptr(f), C, ints(crop), ptr(r), K,
-        float(spatial_scale), pooled_height, pooled_width, pooled_zsize, int(sampling_ratio), ptr(out),
-        stream_of()))
-    return out
+    return _RoiSparseFn.apply(feat_s3d.features, r, feat_s3d.metadata, feat_s3d.spatial_size.tolist(),
+                              [int(c) for c in crop], spatial_scale, pooled_height, pooled_width, pooled_zsize,
+                              sampling_ratio)
 
 
 class ROIAlignRotated3D(torch.nn.Module):
@@ -49,7 +72,6 @@ class ROIAlignRotated3D(torch.nn.Module):
         self.spatial_scale = spatial_scale
         self.sampling_ratio = sampling_ratio
 
-    @torch.no_grad()
     def forward(self, input, rois):
         ph, pw, pz = self.output_size
         if hasattr(input, "metadata"):

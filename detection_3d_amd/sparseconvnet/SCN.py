@@ -4,7 +4,8 @@
 empty and resized by the callee), but every call lands in libd3d_hip.so on the current HIP stream
 -- including the rulebook construction, which the reference does on the CPU.
 
-Inference (forward) entry points only in this round; *_backward raise NotImplementedError.
+Forward and backward entry points of the ops FPN_Net uses (SparseToDense has no backward: the detector
+never densifies).
 """
 import ctypes
 import os
@@ -321,13 +322,98 @@ def SparseToDense_updateOutput(spatial_size, m, input_features, output, nPlanes,
                                             int(batch_size), ptr(output), stream_of()))
 
 
-def _no_backward(*a, **k):
-    raise NotImplementedError("backward entry points are not built in this round (SURVEY.md 8(a) a7)")
+def pack_weight_transposed(weight, flip):
+    """Packing of W^T ([fv, 1, Cin, Cout] -> a conv weight with Cin'=Cout, Cout'=Cin; `flip` reverses the
+    offset order, needed for the submanifold dInput)."""
+    require_gpu(weight)
+    fv, groups, cin, cout = weight.shape
+    n = lib().d3d_packed_weight_floats(fv, cout, cin)
+    if n == 0:
+        raise _lib.D3DError(f"unsupported conv shape for backward fv={fv} Cin={cin} Cout={cout}")
+    packed = torch.empty(n, dtype=torch.float32, device=weight.device)
+    check(lib().d3d_pack_conv_weight_transposed(ptr(weight.detach()), fv, cin, cout, int(bool(flip)), ptr(packed),
+                                                stream_of()))
+    return packed
 
 
-InputLayer_updateGradInput = _no_backward
-SubmanifoldConvolution_backward = _no_backward
-Convolution_backward = _no_backward
-Deconvolution_backward = _no_backward
-BatchNormalization_backward = _no_backward
-SparseToDense_updateGradInput = _no_backward
+def _dinput_supported(cin):
+    return cin in (32, 64, 128, 256)
+
+
+def SubmanifoldConvolution_backward(spatial_size, filter_size, m, input_features, d_input_features,
+                                    d_output_features, weight, d_weight, d_bias, want_d_input=True):
+    """sparseconvnet.h:106-111.  d_input_features is resized and overwritten, d_weight (pre-zeroed by the
+    caller, submanifoldConvolution.py backward) is accumulated into."""
+    require_gpu(input_features, d_output_features, weight, d_weight)
+    fv, _, cin, cout = weight.shape
+    size, filt = _size3(spatial_size), _size3(filter_size)
+    do = d_output_features.contiguous()
+    din = None
+    packed_t = None
+    if want_d_input:
+        if not _dinput_supported(cin):
+            raise _lib.D3DError(f"dInput for Cin={cin} is not built (only the first layer has such a Cin)")
+        d_input_features.resize_(input_features.shape[0], cin)
+        din = d_input_features
+        packed_t = pack_weight_transposed(weight, flip=True)
+    check(lib().d3d_subm_conv_backward(m._h, ints(size), ints(filt), ptr(input_features), cin, ptr(packed_t), cout,
+                                       ptr(do), ptr(din), ptr(d_weight), stream_of()))
+
+
+def Convolution_backward(input_size, output_size, filter_size, filter_stride, m, input_features,
+                         d_input_features, d_output_features, weight, d_weight, d_bias, want_d_input=True):
+    """sparseconvnet.h:92-98."""
+    require_gpu(input_features, d_output_features, weight, d_weight)
+    fv, _, cin, cout = weight.shape
+    isz, osz, filt, st = _size3(input_size), _size3(output_size), _size3(filter_size), _size3(filter_stride)
+    do = d_output_features.contiguous()
+    din = packed_t = None
+    if want_d_input:
+        d_input_features.resize_(input_features.shape[0], cin)
+        din = d_input_features
+        packed_t = pack_weight_transposed(weight, flip=False)
+    check(lib().d3d_conv_backward(m._h, ints(isz), ints(osz), ints(filt), ints(st), ptr(input_features), cin,
+                                  ptr(packed_t), cout, ptr(do), ptr(din), ptr(d_weight), stream_of()))
+
+
+def Deconvolution_backward(input_size, output_size, filter_size, filter_stride, m, input_features,
+                           d_input_features, d_output_features, weight, d_weight, d_bias, want_d_input=True):
+    """sparseconvnet.h:153-158."""
+    require_gpu(input_features, d_output_features, weight, d_weight)
+    fv, _, cin, cout = weight.shape
+    isz, osz, filt, st = _size3(input_size), _size3(output_size), _size3(filter_size), _size3(filter_stride)
+    do = d_output_features.contiguous()
+    din = packed_t = None
+    if want_d_input:
+        d_input_features.resize_(input_features.shape[0], cin)
+        din = d_input_features
+        packed_t = pack_weight_transposed(weight, flip=False)
+    check(lib().d3d_deconv_backward(m._h, ints(isz), ints(osz), ints(filt), ints(st), ptr(input_features), cin,
+                                    ptr(packed_t), cout, ptr(do), ptr(din), ptr(d_weight), stream_of()))
+
+
+def BatchNormalization_backward(input_features, d_input_features, output_features, d_output_features,
+                                saveMean, saveInvStd, runningMean, runningVar, weight, bias, d_weight, d_bias,
+                                leakiness):
+    """sparseconvnet.h:27-32 (d_output_features is NOT modified in place, unlike the reference)."""
+    require_gpu(input_features, output_features, d_output_features, saveMean, saveInvStd)
+    rows, planes = input_features.shape
+    d_input_features.resize_(rows, planes)
+    w = weight if (weight is not None and weight.numel()) else None
+    nbytes = lib().d3d_bn_backward_scratch_bytes(planes)
+    scratch = _scratch(input_features.device, nbytes)
+    check(lib().d3d_bn_backward(ptr(input_features), ptr(output_features), ptr(d_output_features.contiguous()),
+                                ptr(d_input_features), rows, planes, ptr(saveMean), ptr(saveInvStd), ptr(w),
+                                ptr(d_weight), ptr(d_bias), float(leakiness), ptr(scratch), scratch.numel(),
+                                stream_of()))
+
+
+def InputLayer_updateGradInput(m, d_input_features, d_output_features):
+    """sparseconvnet.h:164-167; d_input_features must be sized [n_points, planes] by the caller."""
+    require_gpu(d_input_features, d_output_features)
+    check(lib().d3d_input_layer_backward(m._h, ptr(d_output_features.contiguous()), d_output_features.shape[1],
+                                         ptr(d_input_features), stream_of()))
+
+
+def SparseToDense_updateGradInput(*a, **k):
+    raise NotImplementedError("the detector samples RoIs through the hash grid; SparseToDense has no backward here")

@@ -2,7 +2,8 @@
 parameter names/shapes and forward semantics of SparseConvNet/sparseconvnet/*.py so that
 reference checkpoints load unchanged (checkpoint surface).
 
-Forward only (inference) in this round: all ops run under torch.no_grad().
+Every op is a torch.autograd.Function whose forward / backward call libd3d_hip.so (the reference's
+sparseconvnet/*.py wrap the pybind calls the same way).
 """
 import torch
 from torch.nn import Module, Parameter
@@ -56,6 +57,86 @@ def _like(inp, features, spatial_size=None):
     return SparseConvNetTensor(features, inp.metadata, inp.spatial_size if spatial_size is None else spatial_size)
 
 
+class _InputLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, metadata, spatial_size, coords, batch_size, mode):
+        out = feats.new_empty(0)
+        SCN.InputLayer_updateOutput(metadata, spatial_size, coords, feats, out, batch_size, mode)
+        ctx.meta_obj, ctx.n_points = metadata, feats.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        d_in = d_out.new_zeros((ctx.n_points, d_out.shape[1]))
+        SCN.InputLayer_updateGradInput(ctx.meta_obj, d_in, d_out)
+        return d_in, None, None, None, None, None
+
+
+class _ConvFn(torch.autograd.Function):
+    """kind 0 submanifold, 1 strided convolution, 2 deconvolution.  `residual` (optional) is added in the
+    forward epilogue; its gradient is d_out."""
+
+    @staticmethod
+    def forward(ctx, feats, weight, residual, kind, metadata, in_size, out_size, filter_size, filter_stride, packed):
+        out = feats.new_empty(0)
+        res = None if residual is None else residual.contiguous()
+        if kind == 0:
+            SCN.SubmanifoldConvolution_updateOutput(in_size, filter_size, metadata, feats, out, weight, None,
+                                                    packed=packed, residual=res)
+        elif kind == 1:
+            SCN.Convolution_updateOutput(in_size, out_size, filter_size, filter_stride, metadata, feats, out, weight,
+                                         None, packed=packed)
+        else:
+            SCN.Deconvolution_updateOutput(in_size, out_size, filter_size, filter_stride, metadata, feats, out,
+                                           weight, None, packed=packed, residual=res)
+        ctx.save_for_backward(feats, weight)
+        ctx.args = (kind, metadata, in_size, out_size, filter_size, filter_stride, residual is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        feats, weight = ctx.saved_tensors
+        kind, metadata, in_size, out_size, filter_size, filter_stride, has_res = ctx.args
+        d_out = d_out.contiguous()
+        want_in = ctx.needs_input_grad[0]
+        d_in = feats.new_empty(0)
+        d_w = torch.zeros_like(weight)
+        if kind == 0:
+            SCN.SubmanifoldConvolution_backward(in_size, filter_size, metadata, feats, d_in, d_out, weight, d_w, None,
+                                                want_d_input=want_in)
+        elif kind == 1:
+            SCN.Convolution_backward(in_size, out_size, filter_size, filter_stride, metadata, feats, d_in, d_out,
+                                     weight, d_w, None, want_d_input=want_in)
+        else:
+            SCN.Deconvolution_backward(in_size, out_size, filter_size, filter_stride, metadata, feats, d_in, d_out,
+                                       weight, d_w, None, want_d_input=want_in)
+        return (d_in if want_in else None, d_w, d_out if has_res else None, None, None, None, None, None, None, None)
+
+
+class _BatchNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, weight, bias, running_mean, running_var, eps, momentum, train, leakiness):
+        out = feats.new_empty(0)
+        save_mean = feats.new_empty(running_mean.shape[0])
+        save_invstd = feats.new_empty(running_mean.shape[0])
+        SCN.BatchNormalization_updateOutput(feats, out, save_mean, save_invstd, running_mean, running_var, weight, bias,
+                                            eps, momentum, train, leakiness)
+        ctx.save_for_backward(feats, out, weight, save_mean, save_invstd)
+        ctx.leakiness = leakiness
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        feats, out, weight, save_mean, save_invstd = ctx.saved_tensors
+        d_in = feats.new_empty(0)
+        d_w = torch.zeros_like(save_mean)
+        d_b = torch.zeros_like(save_mean)
+        SCN.BatchNormalization_backward(feats, d_in, out, d_out, save_mean, save_invstd, None, None, weight, None,
+                                        d_w, d_b, ctx.leakiness)
+        has_w = weight is not None
+        return d_in, (d_w if has_w else None), (d_b if has_w else None), None, None, None, None, None, None
+
+
 class _PackedWeightMixin(object):
     """Caches the MFMA-layout copy of `weight` until the parameter changes."""
 
@@ -82,13 +163,11 @@ class InputLayer(Module):
         self.device = device
         return self
 
-    @torch.no_grad()
     def forward(self, input):
         out = SparseConvNetTensor(metadata=Metadata(self.dimension), spatial_size=self.spatial_size)
         feats = input[1].to(self.device) if self.device else input[1]
-        out.features = feats.new_empty(0)
-        SCN.InputLayer_updateOutput(out.metadata, self.spatial_size, input[0], feats, out.features,
-                                    0 if len(input) == 2 else input[2], self.mode)
+        out.features = _InputLayerFn.apply(feats, out.metadata, self.spatial_size, input[0],
+                                           0 if len(input) == 2 else input[2], self.mode)
         return out
 
 
@@ -104,15 +183,12 @@ class SubmanifoldConvolution(Module, _PackedWeightMixin):
         std = (2.0 * groups / nIn / self.filter_volume) ** 0.5
         self.weight = Parameter(torch.empty(self.filter_volume, groups, nIn // groups, nOut // groups).normal_(0, std))
 
-    @torch.no_grad()
     def forward(self, input, residual=None):
         assert input.features.nelement() == 0 or input.features.size(1) == self.nIn, (self.nIn, self.nOut)
-        out = _like(input, input.features.new_empty(0))
-        SCN.SubmanifoldConvolution_updateOutput(input.spatial_size, self.filter_size, input.metadata,
-                                                input.features, out.features, self.weight, None,
-                                                packed=self._packed(),
-                                                residual=None if residual is None else residual.features)
-        return out
+        f = _ConvFn.apply(input.features, self.weight, None if residual is None else residual.features, 0,
+                          input.metadata, input.spatial_size, input.spatial_size, self.filter_size, None,
+                          self._packed())
+        return _like(input, f)
 
     def input_spatial_size(self, out_size):
         return out_size
@@ -131,17 +207,14 @@ class Convolution(Module, _PackedWeightMixin):
         std = (2.0 * groups / nIn / self.filter_volume) ** 0.5
         self.weight = Parameter(torch.empty(self.filter_volume, groups, nIn // groups, nOut // groups).normal_(0, std))
 
-    @torch.no_grad()
     def forward(self, input):
         assert input.features.nelement() == 0 or input.features.size(1) == self.nIn
         out_size = (input.spatial_size - self.filter_size) // self.filter_stride + 1
         assert ((out_size - 1) * self.filter_stride + self.filter_size == input.spatial_size).all(), \
             (input.spatial_size, out_size, self.filter_size, self.filter_stride)
-        out = _like(input, input.features.new_empty(0), out_size)
-        SCN.Convolution_updateOutput(input.spatial_size, out_size, self.filter_size, self.filter_stride,
-                                     input.metadata, input.features, out.features, self.weight, None,
-                                     packed=self._packed())
-        return out
+        f = _ConvFn.apply(input.features, self.weight, None, 1, input.metadata, input.spatial_size, out_size,
+                          self.filter_size, self.filter_stride, self._packed())
+        return _like(input, f, out_size)
 
     def input_spatial_size(self, out_size):
         return (out_size - 1) * self.filter_stride + self.filter_size
@@ -160,16 +233,13 @@ class Deconvolution(Module, _PackedWeightMixin):
         std = (2.0 * groups / nIn / self.filter_volume) ** 0.5
         self.weight = Parameter(torch.empty(self.filter_volume, groups, nIn // groups, nOut // groups).normal_(0, std))
 
-    @torch.no_grad()
     def forward(self, input, residual=None):
         assert input.features.nelement() == 0 or input.features.size(1) == self.nIn
         out_size = (input.spatial_size - 1) * self.filter_stride + self.filter_size
-        out = _like(input, input.features.new_empty(0), out_size)
-        SCN.Deconvolution_updateOutput(input.spatial_size, out_size, self.filter_size, self.filter_stride,
-                                       input.metadata, input.features, out.features, self.weight, None,
-                                       packed=self._packed(),
-                                       residual=None if residual is None else residual.features)
-        return out
+        f = _ConvFn.apply(input.features, self.weight, None if residual is None else residual.features, 2,
+                          input.metadata, input.spatial_size, out_size, self.filter_size, self.filter_stride,
+                          self._packed())
+        return _like(input, f, out_size)
 
     def input_spatial_size(self, out_size):
         return (out_size - self.filter_size) // self.filter_stride + 1
@@ -189,22 +259,16 @@ class BatchNormalization(Module):
             self.bias = Parameter(torch.zeros(nPlanes))
         self.track_running_stats = track_running_stats
 
-    @torch.no_grad()
     def forward(self, input):
         f = input.features
         assert f.nelement() == 0 or f.size(1) == self.nPlanes, (self.nPlanes, f.shape)
         if self.training or self.track_running_stats:
             mean, var = self.running_mean, self.running_var
         else:  # batchNormalization.py:53-55: batch statistics stand in for the running ones
-            mean, var = SCN.batch_stats(f)
-        out = _like(input, f.new_empty(0))
-        save_mean = f.new_empty(self.nPlanes)
-        save_invstd = f.new_empty(self.nPlanes)
-        SCN.BatchNormalization_updateOutput(f, out.features, save_mean, save_invstd, mean, var,
-                                            self.weight if self.affine else None,
-                                            self.bias if self.affine else None, self.eps, self.momentum,
-                                            self.training, self.leakiness)
-        return out
+            mean, var = SCN.batch_stats(f.detach())
+        y = _BatchNormFn.apply(f, self.weight if self.affine else None, self.bias if self.affine else None,
+                               mean, var, self.eps, self.momentum, self.training, self.leakiness)
+        return _like(input, y)
 
     def input_spatial_size(self, out_size):
         return out_size
@@ -260,6 +324,10 @@ def add_feature_planes(inputs):
     from .._lib import check, lib, ptr, stream_of
     assert len(inputs) >= 2
     acc = inputs[0].features
+    if torch.is_grad_enabled() and any(i.features.requires_grad for i in inputs):
+        for other in inputs[1:]:
+            acc = acc + other.features
+        return _like(inputs[0], acc)
     for other in inputs[1:]:
         out = torch.empty_like(acc)
         check(lib().d3d_add(ptr(acc), ptr(other.features.contiguous()), ptr(out), acc.numel(), stream_of()))

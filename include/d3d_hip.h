@@ -117,6 +117,40 @@ int d3d_deconv_forward(d3d_meta *m, const int *in_size_host, const int *out_size
                        const float *packed_w, int cout, const float *residual, float *out,
                        void *stream, double *macs_host);
 
+/* a7. Backward (training).  SubmanifoldConvolution_backward / Convolution_backward / Deconvolution_backward
+ * (SCN/sparseconvnet.h:92-98,106-111,153-158; SCN/CUDA/Convolution.cu:249-442): d_in is overwritten,
+ * d_weight [fv, Cin, Cout] is accumulated into (the caller pre-zeroes it, as the reference's Python does).
+ * `packed_wt*` is the transposed packing of d3d_pack_conv_weight_transposed (flip=1 for submanifold).
+ * Either gradient pointer may be null to skip it.  dWeight uses fp32 atomics (like the reference).     */
+int d3d_pack_conv_weight_transposed(const float *w, int filter_volume, int cin, int cout, int flip,
+                                    float *packed, void *stream);   /* size d3d_packed_weight_floats(fv, cout, cin) */
+int d3d_subm_conv_backward(d3d_meta *m, const int *spatial_size_host, const int *filter_host,
+                           const float *in, int cin, const float *packed_wt_flipped, int cout,
+                           const float *d_out, float *d_in, float *d_weight, void *stream);
+int d3d_conv_backward(d3d_meta *m, const int *in_size_host, const int *out_size_host,
+                      const int *filter_host, const int *stride_host, const float *in, int cin,
+                      const float *packed_wt, int cout, const float *d_out, float *d_in,
+                      float *d_weight, void *stream);
+int d3d_deconv_backward(d3d_meta *m, const int *in_size_host, const int *out_size_host,
+                        const int *filter_host, const int *stride_host, const float *in, int cin,
+                        const float *packed_wt, int cout, const float *d_out, float *d_in,
+                        float *d_weight, void *stream);
+/* BatchNormalization_backward (SCN/sparseconvnet.h:27-32; SCN/CPU/BatchNormalization.cpp:62-107). */
+int d3d_bn_backward(const float *in, const float *out, const float *d_out, float *d_in, int rows,
+                    int planes, const float *save_mean, const float *save_invstd, const float *weight,
+                    float *d_weight, float *d_bias, float leakiness, void *scratch,
+                    size_t scratch_bytes, void *stream);
+size_t d3d_bn_backward_scratch_bytes(int planes);
+/* InputLayer_updateGradInput (SCN/sparseconvnet.h:164-167; SCN/CPU/IOLayers.cpp:30-47). */
+int d3d_input_layer_backward(d3d_meta *m, const float *d_out, int planes, float *d_in, void *stream);
+/* roi_align_rotated_3d_backward restricted to the active sites (csrc/cuda/ROIAlignRotated3D_cuda.cu:238-354
+ * followed by SparseToDense_updateGradInput); d_feats [n_active, C] is accumulated into.                */
+int d3d_roi_align_rotated_3d_sparse_backward(d3d_meta *m, const int *spatial_size_host,
+                                             const float *top_diff, int C, const int *crop_host,
+                                             const float *rois, int K, float spatial_scale, int ph,
+                                             int pw, int pz, int sampling_ratio, float *d_feats,
+                                             void *stream);
+
 /* a8. BatchNormalization_updateOutput (SCN/sparseconvnet.h:21-26; SCN/CPU/BatchNormalization.cpp:12-60).
  * train!=0: batch statistics, running update r = m*r + (1-m)*batch.  train==0: uses
  * running_mean / running_var.  d3d_bn_batch_stats computes mean(0) and the UNBIASED var(0)

@@ -156,6 +156,51 @@ def bn_forward(x, running_mean, running_var, weight, bias, eps, momentum, train,
     return out, sm, si, rm, rv
 
 
+def rule_conv_backward(feats, W, rules, d_out, deconv=False):
+    """Returns (d_feats, dW[K,Cin,Cout]) of rule_conv (CPU/Convolution.cpp:81-115)."""
+    feats, W, d_out = _f32(feats), _f32(W), _f32(d_out)
+    K, cin, cout = W.shape
+    rules = _i32(rules)
+    if deconv:
+        rules = np.ascontiguousarray(rules[:, [1, 0, 2]])
+    d_in = np.empty_like(feats)
+    dW = np.empty_like(W)
+    lib().orc_rule_conv_backward(_p(feats), cin, _p(W), K, cout, _p(rules), ctypes.c_long(rules.shape[0]),
+                                 _p(d_out), feats.shape[0], _p(d_in), _p(dW))
+    return d_in, dW
+
+
+def bn_backward(x, out, d_out, save_mean, save_invstd, weight, leakiness):
+    """Returns (d_in, d_weight, d_bias) (CPU/BatchNormalization.cpp:62-107)."""
+    x, out = _f32(x), _f32(out)
+    d_out = _f32(d_out).copy()
+    n, c = x.shape
+    d_in = np.empty_like(x)
+    dw = np.zeros(c, np.float32)
+    db = np.zeros(c, np.float32)
+    w = _f32(weight) if weight is not None else None
+    lib().orc_bn_backward(_p(x), _p(d_in), _p(out), _p(d_out), c, n, _p(_f32(save_mean)), _p(_f32(save_invstd)),
+                          _p(w) if w is not None else None, _p(dw), _p(db), ctypes.c_float(leakiness))
+    return d_in, dw, db
+
+
+def input_backward(d_out, site_of_point, n_active, average=True):
+    d_out = _f32(d_out)
+    sop = _i32(site_of_point)
+    d_in = np.empty((len(sop), d_out.shape[1]), np.float32)
+    lib().orc_input_backward(_p(d_out), d_out.shape[1], _p(sop), len(sop), n_active, int(average), _p(d_in))
+    return d_in
+
+
+def roi_align_rotated_3d_backward(top_diff, rois, spatial_scale, ph, pw, pz, sampling_ratio, dense_shape):
+    top_diff, rois = _f32(top_diff), _f32(rois)
+    B, C, H, W, Z = dense_shape
+    out = np.zeros(dense_shape, np.float32)
+    lib().orc_roi_align_rotated_3d_backward(_p(top_diff), B, C, H, W, Z, _p(rois), rois.shape[0],
+                                            ctypes.c_float(spatial_scale), ph, pw, pz, sampling_ratio, _p(out))
+    return out
+
+
 def sparse_to_dense(feats, loc, size, batch=1):
     feats = _f32(feats)
     loc = _i32(loc)

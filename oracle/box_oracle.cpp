@@ -477,4 +477,65 @@ void orc_roi_align_rotated_3d(const float *input, int B, int C, int H, int W, in
   }
 }
 
+// RoIAlignRotated3DBackwardFeature (ROIAlignRotated3D_cuda.cu:182-354), T=float, into a zeroed dense
+// gradient [B,C,H,W,Z].  Unlike the forward (:27), the backward bound test is `z > zsize` (:190):
+// samples above the map get no gradient.  Serial (the reference uses atomicAdd).
+void orc_roi_align_rotated_3d_backward(const float *top_diff, int B, int C, int H, int W, int Z,
+                                       const float *rois, int K, float spatial_scale, int ph_, int pw_,
+                                       int pz_, int sampling_ratio, float *bottom_diff) {
+  std::memset(bottom_diff, 0, sizeof(float) * (size_t)B * C * H * W * Z);
+  for (int n = 0; n < K; n++) {
+    const float *r = rois + 8 * n;
+    int b = (int)r[0];
+    float cw = r[1] * spatial_scale, ch = r[2] * spatial_scale, cz = r[3] * spatial_scale;
+    float rw = r[4] * spatial_scale, rh = r[5] * spatial_scale, rz = r[6] * spatial_scale;
+    float theta = (float)((double)r[7] * M_PI / 180.0);
+    rw = std::max(rw, 1.f);
+    rh = std::max(rh, 1.f);
+    rz = std::max(rz, 1.f);
+    float bh = rh / (float)ph_, bw = rw / (float)pw_, bz = rz / (float)pz_;
+    int gh = sampling_ratio > 0 ? sampling_ratio : (int)std::ceil(rh / ph_);
+    int gw = sampling_ratio > 0 ? sampling_ratio : (int)std::ceil(rw / pw_);
+    int gz = sampling_ratio > 0 ? sampling_ratio : (int)std::ceil(rz / pz_);
+    float sh = (float)(-rh / 2.0), sw = (float)(-rw / 2.0), sz = (float)(-rz / 2.0);
+    float cosT = (float)std::cos((double)theta), sinT = (float)std::sin((double)theta);
+    const float count = (float)(gh * gw * gz);
+    for (int c = 0; c < C; c++) {
+      float *d = bottom_diff + ((size_t)b * C + c) * H * W * Z;
+      for (int ph = 0; ph < ph_; ph++)
+        for (int pw = 0; pw < pw_; pw++)
+          for (int pz = 0; pz < pz_; pz++) {
+            const float g = top_diff[((((size_t)n * C + c) * ph_ + ph) * pw_ + pw) * pz_ + pz];
+            for (int iy = 0; iy < gh; iy++) {
+              const float yy = sh + ph * bh + (float)(iy + .5f) * bh / (float)gh;
+              for (int ix = 0; ix < gw; ix++) {
+                const float xx = sw + pw * bw + (float)(ix + .5f) * bw / (float)gw;
+                for (int iz = 0; iz < gz; iz++) {
+                  const float zz = sz + pz * bz + (float)(iz + .5f) * bz / (float)gz;
+                  float x = xx * cosT + yy * sinT + cw;
+                  float y = yy * cosT - xx * sinT + ch;
+                  float z = zz + cz;
+                  if (y < -1.0 || y > H || x < -1.0 || x > W || z < -1.0 || z > Z) continue;
+                  if (y <= 0) y = 0;
+                  if (x <= 0) x = 0;
+                  if (z <= 0) z = 0;
+                  int yl = (int)y, xl = (int)x, zl = (int)z, yh, xh, zh;
+                  if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
+                  if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+                  if (zl >= Z - 1) { zh = zl = Z - 1; z = (float)zl; } else zh = zl + 1;
+                  float ly = y - yl, lx = x - xl, lz = z - zl;
+                  float hy = 1. - ly, hx = 1. - lx, hz = 1. - lz;
+                  float w[8] = {hy * hx * hz, hy * lx * hz, ly * hx * hz, ly * lx * hz,
+                                hy * hx * lz, hy * lx * lz, ly * hx * lz, ly * lx * lz};
+                  int yy_[8] = {yl, yl, yh, yh, yl, yl, yh, yh}, xx_[8] = {xl, xh, xl, xh, xl, xh, xl, xh};
+                  int zz_[8] = {zl, zl, zl, zl, zh, zh, zh, zh};
+                  for (int q = 0; q < 8; q++) d[(yy_[q] * W + xx_[q]) * Z + zz_[q]] += g * w[q] / count;
+                }
+              }
+            }
+          }
+    }
+  }
+}
+
 }  // extern "C"

@@ -12,6 +12,12 @@ import oracle
 from detection_3d_amd.synthetic import make_boxes
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _no_grad():
+    with torch.no_grad():
+        yield
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 

@@ -12,6 +12,12 @@ from oracle.detector_port import OracleDetector, nms_clamped
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _no_grad():
+    with torch.no_grad():
+        yield
+
+
 @pytest.fixture(scope="module")
 def setup(dev):
     from detection_3d_amd.config import get_cfg

@@ -9,6 +9,12 @@ import oracle
 from tests.helpers import OracleFPN, canon_rules, nbr_to_rules, small_scene, sort_by_loc
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _no_grad():
+    with torch.no_grad():
+        yield
 RTOL = 1e-4
 
 
