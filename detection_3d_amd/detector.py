@@ -20,6 +20,7 @@ from torch import nn
 
 from . import box_ops
 from . import sparseconvnet as scn
+from . import training as T
 from .config import class_to_label
 from .roi_align_rotated_3d import roi_align_rotated_3d_sparse
 
@@ -116,23 +117,41 @@ class RPNModule(nn.Module):
         self.anchor_generator = AnchorGenerator(cfg)
         self.head = RPNHead(cfg, cfg.MODEL.BACKBONE.OUT_CHANNELS, self.anchor_generator.num_anchors_per_location())
         rpn = cfg.MODEL.RPN
-        self.pre_nms_top_n = rpn.FPN_PRE_NMS_TOP_N_TEST
-        self.post_nms_top_n = rpn.FPN_POST_NMS_TOP_N_TEST
+        self.top_n = {False: (rpn.FPN_PRE_NMS_TOP_N_TEST, rpn.FPN_POST_NMS_TOP_N_TEST),
+                      True: (rpn.FPN_PRE_NMS_TOP_N_TRAIN, rpn.FPN_POST_NMS_TOP_N_TRAIN)}
         self.nms_thresh = rpn.NMS_THRESH
         self.nms_aug_thickness = list(rpn.NMS_AUG_THICKNESS_Y_Z)
+        self.add_gt_proposals = rpn.ADD_GT_PROPOSALS
+        self.loss_evaluator = T.RPNLoss(cfg)
 
     @torch.no_grad()
-    def forward(self, features_sparse):
-        objectness, box_regression = self.head([f.features for f in features_sparse])
-        anchors = torch.cat(self.anchor_generator(features_sparse), 0)
-        assert objectness.shape[0] == box_regression.shape[0] == anchors.shape[0]
+    def select_proposals(self, objectness, box_regression, anchors, train):
+        pre, post = self.top_n[bool(train)]
         scores = objectness.reshape(-1).sigmoid()
-        k = min(self.pre_nms_top_n, scores.shape[0])
+        k = min(pre, scores.shape[0])
         scores_k, idx = scores.topk(k, dim=0, sorted=True)                      # inference_3d.py:109
         proposals = box_ops.box_decode(box_regression[idx], anchors[idx])       # :123
         keep = box_ops.nms_3d_clamped(proposals, scores_k, self.nms_thresh, self.nms_aug_thickness,
-                                      max_proposals=self.post_nms_top_n, flag='rpn_post')
+                                      max_proposals=post, flag='rpn_post')
         return proposals[keep], scores_k[keep]
+
+    def forward(self, features_sparse, targets=None):
+        """eval: (proposals, objectness).  train: (proposals incl. GT boxes, objectness, loss dict)
+        (rpn_sparse3d.py:233-270, rpn/inference_3d.py:53-80,180-199)."""
+        objectness, box_regression = self.head([f.features for f in features_sparse])
+        with torch.no_grad():
+            anchors = torch.cat(self.anchor_generator(features_sparse), 0)
+        assert objectness.shape[0] == box_regression.shape[0] == anchors.shape[0]
+        proposals, scores = self.select_proposals(objectness.detach(), box_regression.detach(), anchors,
+                                                  self.training)
+        if not self.training:
+            return proposals, scores
+        gt = targets["bbox3d"]
+        if self.add_gt_proposals and gt.shape[0]:
+            proposals = torch.cat([proposals, gt], 0)
+            scores = torch.cat([scores, torch.ones(gt.shape[0], device=scores.device)], 0)
+        loss_obj, loss_reg = self.loss_evaluator(anchors, objectness.reshape(-1), box_regression, gt)
+        return proposals, scores, {"loss_objectness": loss_obj, "loss_rpn_box_reg": loss_reg}
 
 
 # ----------------------------------------------------------------------------------------------
@@ -279,7 +298,7 @@ class PostProcessor(nn.Module):
 
 
 class ROIBoxHead3D(nn.Module):
-    """roi_heads/box_head_3d/box_head.py (test path)."""
+    """roi_heads/box_head_3d/box_head.py."""
 
     def __init__(self, cfg):
         super().__init__()
@@ -287,10 +306,18 @@ class ROIBoxHead3D(nn.Module):
         self.predictor = FPNPredictor(cfg)
         self.post_processor = PostProcessor(cfg)
 
-    def forward(self, roi_features, proposals):
+        self.loss_evaluator = T.ROILoss(cfg)
+
+    def forward(self, roi_features, proposals, targets=None):
+        if self.training:                                                        # box_head.py:96-149
+            proposals, labels, reg_targets = self.loss_evaluator.subsample(proposals, targets["bbox3d"],
+                                                                           targets["labels"])
         x = self.feature_extractor(roi_features, proposals)
         logits, reg = self.predictor(x)
-        return self.post_processor(logits, reg, proposals)
+        if not self.training:
+            return self.post_processor(logits, reg, proposals)
+        cls_loss, box_loss = self.loss_evaluator(logits, reg, proposals, labels, reg_targets)
+        return {"loss_classifier_roi": cls_loss, "loss_box_reg_roi": box_loss}
 
 
 class _RoiHeads(nn.Module):
@@ -312,8 +339,22 @@ class SparseRCNN(nn.Module):
         self.roi_heads = _RoiHeads(cfg)
         self.class_to_label = class_to_label(cfg.INPUT.CLASSES)
 
-    @torch.no_grad()
-    def forward(self, points, return_intermediates=False):
+    def forward(self, points, targets=None, return_intermediates=False):
+        """eval: detections dict.  train: dict of the four losses (targets = {"bbox3d" [M,7] yx_zb, "labels" [M]})."""
+        if self.training:
+            if targets is None:
+                raise ValueError("In training mode, targets should be passed")
+            rpn_features, roi_features = self.backbone(points)
+            proposals, _, rpn_losses = self.rpn(rpn_features, targets)
+            proposals = proposals.clone()
+            proposals[:, 3:6] = torch.clamp(proposals[:, 3:6], min=0.001)
+            losses = dict(self.roi_heads.box(roi_features, proposals, targets))
+            losses.update(rpn_losses)
+            return losses
+        with torch.no_grad():
+            return self._forward_eval(points, return_intermediates)
+
+    def _forward_eval(self, points, return_intermediates=False):
         rpn_features, roi_features = self.backbone(points)
         proposals, objectness = self.rpn(rpn_features)
         proposals = proposals.clone()

@@ -49,3 +49,35 @@ def make_boxes(seed=0, n=2000, extent=(25.0, 19.0, 2.7)):
     b[:, 6] = base[rng.randint(0, 5, n)] + rng.randn(n) * 0.02
     scores = rng.rand(n)
     return b.astype(np.float32), scores.astype(np.float32)
+
+
+def make_targets(seed=0, extent=(25.0, 19.0, 2.7)):
+    """Ground-truth boxes of the synthetic building of make_scene: one wall per x / y plane (yx_zb mode:
+    xc, yc, z_bot, thickness, length, height, yaw; yaw 0 = length along x) plus random windows and doors on
+    them.  Labels follow data3d/suncg_utils/suncg_metas.py: wall 1, window 2, door 3."""
+    rng = np.random.RandomState(seed + 12345)
+    ex, ey, ez = extent
+    xs = np.linspace(0.05, ex - 0.05, 6)
+    ys = np.linspace(0.05, ey - 0.05, 4)
+    boxes, labels = [], []
+    for x in xs:
+        boxes.append([x, ey / 2, 0.0, 0.1, ey, ez, -np.pi / 2])
+        labels.append(1)
+    for y in ys:
+        boxes.append([ex / 2, y, 0.0, 0.1, ex, ez, 0.0])
+        labels.append(1)
+    for _ in range(12):
+        if rng.rand() < 0.5:
+            x = xs[rng.randint(len(xs))]
+            c = [x, rng.uniform(1, ey - 1), 0.0, 0.12, 0.0, 0.0, -np.pi / 2]
+        else:
+            y = ys[rng.randint(len(ys))]
+            c = [rng.uniform(1, ex - 1), y, 0.0, 0.12, 0.0, 0.0, 0.0]
+        if rng.rand() < 0.5:      # window
+            c[2], c[4], c[5] = 0.9, rng.uniform(0.8, 1.8), rng.uniform(0.8, 1.4)
+            labels.append(2)
+        else:                     # door
+            c[2], c[4], c[5] = 0.0, rng.uniform(0.8, 1.2), rng.uniform(1.9, 2.2)
+            labels.append(3)
+        boxes.append(c)
+    return np.asarray(boxes, np.float32), np.asarray(labels, np.int64)

@@ -38,15 +38,16 @@ b[:, 6] = (b[:, 6] - 0.5) * 3.0
 bl = BoxList3D(b.clone(), None, "yx_zb", None, {"prediction": True})
 out["conv_yxzb"] = bl.bbox3d.numpy().copy()
 out["conv_standard"] = bl.convert("standard").bbox3d.numpy().copy()
-# modeling/matcher.py (training rows; used from round 2 on)
+# modeling/matcher.py:58-177: RPN-style (low-quality matches + ignore-nearby + yaw mask) and ROI-style
 iou = torch.rand(37, 900) ** 3
-m = Matcher(0.55, 0.2, allow_low_quality_matches=True, yaw_threshold=math.pi)
-try:
-    res = m(iou.clone())
-    out["match_iou"] = iou.numpy()
-    out["match_res"] = res.numpy() if isinstance(res, torch.Tensor) else np.asarray(res[0])
-except Exception as e:  # signature differs between forks; record nothing
-    print("Matcher not recorded:", type(e).__name__, e)
+out["match_iou"] = iou.numpy()
+out["match_res"] = Matcher(0.55, 0.2, allow_low_quality_matches=True, yaw_threshold=math.pi)(iou.clone()).numpy()
+iou2 = (torch.rand(23, 4000) ** 8) * 0.9
+iou2[torch.arange(23), torch.randint(0, 4000, (23,))] = 0.3 + 0.6 * torch.rand(23)
+yaw = torch.rand(23, 4000) * 1.5
+out["match2_iou"], out["match2_yaw"] = iou2.numpy(), yaw.numpy()
+out["match2_rpn"] = Matcher(0.55, 0.2, allow_low_quality_matches=True, yaw_threshold=0.7)(iou2.clone(), yaw_diff=yaw).numpy()
+out["match2_roi"] = Matcher(0.5, 0.5, allow_low_quality_matches=False)(iou2.clone()).numpy()
 np.savez_compressed(os.path.join(HERE, "ref_python.npz"), **out)
 
 rooms = {}
