@@ -56,6 +56,11 @@ _SIGS = {
                                        ctypes.c_float, vp, ctypes.c_size_t, vp]),
     "d3d_bn_backward_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "d3d_input_layer_backward": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, vp]),
+    "d3d_sparse_to_dense_backward": (ctypes.c_int, [vp, c_int_p, vp, ctypes.c_int, vp, vp]),
+    "d3d_roi_align_rotated_3d_backward": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                         ctypes.c_int, vp, ctypes.c_int, ctypes.c_float,
+                                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                         vp, vp]),
     "d3d_roi_align_rotated_3d_sparse_backward": (ctypes.c_int, [vp, c_int_p, vp, ctypes.c_int, c_int_p, vp,
                                                                 ctypes.c_int, ctypes.c_float, ctypes.c_int,
                                                                 ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -460,6 +460,17 @@ __global__ void k_sparse_to_dense(const float *__restrict__ in, int planes,
   size_t off = ((size_t)p[0] * sy + p[1]) * sz + p[2];
   out[((size_t)p[3] * planes + c) * vol + off] = in[(size_t)i * planes + c];
 }
+// SparseToDense backward (CPU/SparseToDense.cpp:22-33): d_in[i][c] = d_out[dense cell of site i][c]
+__global__ void k_sparse_to_dense_bwd(const float *__restrict__ d_out, int planes, const int32_t *__restrict__ loc,
+                                      int n, int sx, int sy, int sz, float *__restrict__ d_in) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)n * planes) return;
+  int i = (int)(t % n), c = (int)(t / n);
+  const int32_t *p = loc + (size_t)i * 4;
+  size_t vol = (size_t)sx * sy * sz;
+  size_t off = ((size_t)p[0] * sy + p[1]) * sz + p[2];
+  d_in[(size_t)i * planes + c] = d_out[((size_t)p[3] * planes + c) * vol + off];
+}
 __global__ void k_export_plan(const int32_t *__restrict__ nbrT, const int32_t *__restrict__ rows,
                               int npos, int K, int swap, int32_t *triples, long capacity,
                               unsigned long long *count) {
@@ -948,6 +959,23 @@ int d3d_sparse_to_dense_forward(d3d_meta *m, const int *size, const float *in, i
   if (g->n == 0) return D3D_OK;
   D3D_REQUIRE(in, "null input");
   hipLaunchKernelGGL(k_sparse_to_dense, grid1d((long)g->n * planes), dim3(256), 0, s, in, planes, g->loc, g->n, size[0], size[1], size[2], out);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+int d3d_sparse_to_dense_backward(d3d_meta *m, const int *size, const float *d_out, int planes, float *d_in,
+                                 void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(m && size && planes > 0, "bad arguments");
+  Grid *g = find_grid(m, size);
+  if (!g) {
+    set_error("sparse_to_dense backward: no grid of spatial size [%d,%d,%d]", size[0], size[1], size[2]);
+    return D3D_ERR_STATE;
+  }
+  if (g->n == 0) return D3D_OK;
+  D3D_REQUIRE(d_out && d_in, "null pointer");
+  hipLaunchKernelGGL(k_sparse_to_dense_bwd, grid1d((long)g->n * planes), dim3(256), 0, s, d_out, planes, g->loc, g->n,
+                     size[0], size[1], size[2], d_in);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }

@@ -169,6 +169,40 @@ __global__ __launch_bounds__(256) void k_roi_sparse(
   for (int idx = threadIdx.x; idx < nch * NB; idx += 256) o[idx] = tile[(idx / NB) * LD + idx % NB];
 }
 
+// Dense backward, _C.roi_align_rotated_3d_backward (ROIAlignRotated3D_cuda.cu:238-354): one thread per
+// pooled element, 8 fp32 atomics per sub-sample into the zeroed dense gradient.
+__global__ __launch_bounds__(256) void k_roi_dense_bwd(const float *__restrict__ top_diff, int C, int H, int W,
+                                                       int Z, const float *__restrict__ rois, long nthreads,
+                                                       float spatial_scale, int PH, int PW, int PZ,
+                                                       int sampling_ratio, float *__restrict__ bottom_diff) {
+  long index = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (index >= nthreads) return;
+  const int pz = index % PZ;
+  const int pw = (index / PZ) % PW;
+  const int ph = (index / PZ / PW) % PH;
+  const int c = (index / PZ / PW / PH) % C;
+  const int n = index / PZ / PW / PH / C;
+  const RoiGeom g = roi_geom(rois + (size_t)n * 8, spatial_scale, PH, PW, PZ, sampling_ratio);
+  float *d = bottom_diff + ((size_t)g.b * C + c) * H * W * Z;
+  const float count = (float)(g.gh * g.gw * g.gz);
+  const float top = top_diff[index];
+  for (int iy = 0; iy < g.gh; iy++)
+    for (int ix = 0; ix < g.gw; ix++)
+      for (int iz = 0; iz < g.gz; iz++) {
+        float y, x, z;
+        sample_pos(g, ph, pw, pz, iy, ix, iz, y, x, z);
+        Tri t;
+        if (z > Z || !tri_setup(y, x, z, H, W, Z, t)) continue;   // backward bound test (:190)
+        const float w[8] = {t.hy * t.hx * t.hz, t.hy * t.lx * t.hz, t.ly * t.hx * t.hz, t.ly * t.lx * t.hz,
+                            t.hy * t.hx * t.lz, t.hy * t.lx * t.lz, t.ly * t.hx * t.lz, t.ly * t.lx * t.lz};
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const int yy = (q >> 1) & 1 ? t.yh : t.yl, xx = q & 1 ? t.xh : t.xl, zz = q >> 2 ? t.zh : t.zl;
+          atomicAdd(d + ((size_t)yy * W + xx) * Z + zz, top * w[q] / count);
+        }
+      }
+}
+
 // Backward of the sparse variant: the dense gradient of RoIAlignRotated3DBackwardFeature (:238-354)
 // restricted to the active sites (what SparseToDense_updateGradInput would gather back).  Keeps the
 // backward's own bound test `z > zsize` (:190).  fp32 atomics, like the reference.
@@ -256,6 +290,22 @@ int d3d_roi_align_rotated_3d_sparse_forward(d3d_meta *m, const int *size, const 
   size_t lds = (size_t)kRoiCch * (NB + 1) * sizeof(float);
   D3D_REQUIRE(lds <= 64 * 1024, "roi_align_sparse: pooled volume %d too large", NB);
   hipLaunchKernelGGL(k_roi_sparse, dim3(K, (C + kRoiCch - 1) / kRoiCch), dim3(256), lds, s, g.tab, g.cap, feats, C, crop[0], crop[1], crop[2], rois, spatial_scale, ph, pw, pz, sampling_ratio, out);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+int d3d_roi_align_rotated_3d_backward(const float *top_diff, int B, int C, int H, int W, int Z,
+                                      const float *rois, int K, float spatial_scale, int ph, int pw, int pz,
+                                      int sampling_ratio, float *bottom_diff, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Z > 0 && K >= 0 && ph > 0 && pw > 0 && pz > 0 && bottom_diff,
+              "roi_align_backward: bad arguments");
+  D3D_HIP_CHECK(hipMemsetAsync(bottom_diff, 0, sizeof(float) * (size_t)B * C * H * W * Z, s));
+  if (K == 0) return D3D_OK;
+  D3D_REQUIRE(top_diff && rois, "roi_align_backward: null pointer");
+  long nthreads = (long)K * C * ph * pw * pz;
+  hipLaunchKernelGGL(k_roi_dense_bwd, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, top_diff, C, H, W, Z,
+                     rois, nthreads, spatial_scale, ph, pw, pz, sampling_ratio, bottom_diff);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }

@@ -6,19 +6,48 @@ import torch
 from ._lib import check, ints, lib, ptr, require_gpu, stream_of
 
 
+def roi_align_rotated_3d_backward(grad, rois, spatial_scale, pooled_height, pooled_width, pooled_zsize,
+                                  batch_size, channels, height, width, zsize, sampling_ratio):
+    """_C.roi_align_rotated_3d_backward (csrc/ROIAlignRotated3D.h:28-47) -> dense gradient [B,C,H,W,Z]."""
+    g = grad.detach().to(torch.float32).contiguous()
+    r = rois.detach().to(torch.float32).contiguous()
+    require_gpu(g, r)
+    out = torch.empty((batch_size, channels, height, width, zsize), dtype=torch.float32, device=g.device)
+    check(lib().d3d_roi_align_rotated_3d_backward(ptr(g), batch_size, channels, height, width, zsize, ptr(r),
+                                                  r.shape[0], float(spatial_scale), pooled_height, pooled_width,
+                                                  pooled_zsize, int(sampling_ratio), ptr(out), stream_of()))
+    return out
+
+
+class _RoiDenseFn(torch.autograd.Function):
+    """layers/roi_align_rotated_3d.py:11-51 (_ROIAlignRotated3D)."""
+
+    @staticmethod
+    def forward(ctx, inp, rois, spatial_scale, ph, pw, pz, sampling_ratio):
+        B, C, H, W, Z = inp.shape
+        K = rois.shape[0]
+        out = torch.empty((K, C, ph, pw, pz), dtype=torch.float32, device=inp.device)
+        check(lib().d3d_roi_align_rotated_3d_forward(ptr(inp), B, C, H, W, Z, ptr(rois), K, float(spatial_scale),
+                                                     ph, pw, pz, int(sampling_ratio), ptr(out), stream_of()))
+        ctx.save_for_backward(rois)
+        ctx.args = (spatial_scale, ph, pw, pz, sampling_ratio, tuple(inp.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        (rois,) = ctx.saved_tensors
+        spatial_scale, ph, pw, pz, sampling_ratio, shape = ctx.args
+        d = roi_align_rotated_3d_backward(grad, rois, spatial_scale, ph, pw, pz, *shape, sampling_ratio)
+        return d, None, None, None, None, None, None
+
+
 def roi_align_rotated_3d_forward(input, rois, spatial_scale, pooled_height, pooled_width, pooled_zsize,
                                  sampling_ratio):
     """input [B,C,H,W,Z] fp32, rois [K,8] = (batch, cw, ch, cz, w, h, z, theta_deg) -> [K,C,ph,pw,pz]."""
-    inp = input.detach().to(torch.float32).contiguous()
+    inp = input.to(torch.float32).contiguous()
     r = rois.detach().to(torch.float32).contiguous()
     require_gpu(inp, r)
-    B, C, H, W, Z = inp.shape
-    K = r.shape[0]
-    out = torch.empty((K, C, pooled_height, pooled_width, pooled_zsize), dtype=torch.float32, device=inp.device)
-    check(lib().d3d_roi_align_rotated_3d_forward(ptr(inp), B, C, H, W, Z, ptr(r), K, float(spatial_scale),
-                                                 pooled_height, pooled_width, pooled_zsize,
-                                                 int(sampling_ratio), ptr(out), stream_of()))
-    return out
+    return _RoiDenseFn.apply(inp, r, spatial_scale, pooled_height, pooled_width, pooled_zsize, sampling_ratio)
 
 
 class _RoiSparseFn(torch.autograd.Function):

@@ -4,8 +4,7 @@
 empty and resized by the callee), but every call lands in libd3d_hip.so on the current HIP stream
 -- including the rulebook construction, which the reference does on the CPU.
 
-Forward and backward entry points of the ops FPN_Net uses (SparseToDense has no backward: the detector
-never densifies).
+Forward and backward entry points of the ops the 3-D detection path uses.
 """
 import ctypes
 import os
@@ -415,5 +414,9 @@ def InputLayer_updateGradInput(m, d_input_features, d_output_features):
                                          ptr(d_input_features), stream_of()))
 
 
-def SparseToDense_updateGradInput(*a, **k):
-    raise NotImplementedError("the detector samples RoIs through the hash grid; SparseToDense has no backward here")
+def SparseToDense_updateGradInput(spatial_size, m, input_features, d_input_features, d_output):
+    """sparseconvnet.h:218-222."""
+    require_gpu(input_features, d_output)
+    d_input_features.resize_(input_features.shape[0], input_features.shape[1])
+    check(lib().d3d_sparse_to_dense_backward(m._h, ints(_size3(spatial_size)), ptr(d_output.contiguous()),
+                                             input_features.shape[1], ptr(d_input_features), stream_of()))

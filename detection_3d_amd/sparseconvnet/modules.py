@@ -137,6 +137,23 @@ class _BatchNormFn(torch.autograd.Function):
         return d_in, (d_w if has_w else None), (d_b if has_w else None), None, None, None, None, None, None
 
 
+class _SparseToDenseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, metadata, spatial_size, n_planes, batch_size):
+        out = feats.new_empty(0)
+        SCN.SparseToDense_updateOutput(spatial_size, metadata, feats, out, n_planes, batch_size)
+        ctx.save_for_backward(feats)
+        ctx.args = (metadata, spatial_size)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        (feats,) = ctx.saved_tensors
+        d_in = feats.new_empty(0)
+        SCN.SparseToDense_updateGradInput(ctx.args[1], ctx.args[0], feats, d_in, grad)
+        return d_in, None, None, None, None
+
+
 class _PackedWeightMixin(object):
     """Caches the MFMA-layout copy of `weight` until the parameter changes."""
 
@@ -363,12 +380,8 @@ class SparseToDense(Module):
         Module.__init__(self)
         self.dimension, self.nPlanes = dimension, nPlanes
 
-    @torch.no_grad()
     def forward(self, input, batch_size=None):
         if batch_size is None:
             loc = input.get_spatial_locations()
             batch_size = int(loc[:, 3].max().item()) + 1 if loc.shape[0] else 1
-        out = input.features.new_empty(0)
-        SCN.SparseToDense_updateOutput(input.spatial_size, input.metadata, input.features, out,
-                                       self.nPlanes, batch_size)
-        return out
+        return _SparseToDenseFn.apply(input.features, input.metadata, input.spatial_size, self.nPlanes, batch_size)

@@ -143,6 +143,15 @@ int d3d_bn_backward(const float *in, const float *out, const float *d_out, float
 size_t d3d_bn_backward_scratch_bytes(int planes);
 /* InputLayer_updateGradInput (SCN/sparseconvnet.h:164-167; SCN/CPU/IOLayers.cpp:30-47). */
 int d3d_input_layer_backward(d3d_meta *m, const float *d_out, int planes, float *d_in, void *stream);
+/* SparseToDense_updateGradInput (SCN/sparseconvnet.h:218-222): d_in [n_active, planes] gathered from the
+ * dense gradient [batch, planes, X, Y, Z].                                                          */
+int d3d_sparse_to_dense_backward(d3d_meta *m, const int *spatial_size_host, const float *d_out, int planes,
+                                 float *d_in, void *stream);
+/* _C.roi_align_rotated_3d_backward (maskrcnn_benchmark/csrc/ROIAlignRotated3D.h:28-47): bottom_diff
+ * [B,C,H,W,Z] is zeroed and accumulated into with fp32 atomics.                                      */
+int d3d_roi_align_rotated_3d_backward(const float *top_diff, int B, int C, int H, int W, int Z,
+                                      const float *rois, int K, float spatial_scale, int ph, int pw,
+                                      int pz, int sampling_ratio, float *bottom_diff, void *stream);
 /* roi_align_rotated_3d_backward restricted to the active sites (csrc/cuda/ROIAlignRotated3D_cuda.cu:238-354
  * followed by SparseToDense_updateGradInput); d_feats [n_active, C] is accumulated into.                */
 int d3d_roi_align_rotated_3d_sparse_backward(d3d_meta *m, const int *spatial_size_host,

@@ -128,3 +128,34 @@ def test_roi_align_sparse_backward(dev):
     want = dense[0][:, loc[:, 0], loc[:, 1], loc[:, 2]].T
     assert rel(feats.grad.cpu().numpy(), want) < 1e-4
     assert np.abs(want).max() > 0
+
+
+def test_dense_roi_align_and_sparse_to_dense_backward(dev):
+    """The reference's own composition: SparseToDense -> _C.roi_align_rotated_3d (dense), both differentiable;
+    must equal the sparse-sampled op's gradient."""
+    from detection_3d_amd import sparseconvnet as scn
+    from detection_3d_amd.roi_align_rotated_3d import roi_align_rotated_3d_forward, roi_align_rotated_3d_sparse
+    t, ft, x, sop, loc = _sparse_input(dev, 64, seed=9, n_points=5000, size=(32, 32, 8))
+    rng = np.random.RandomState(3)
+    K = 25
+    rois = np.zeros((K, 8), np.float32)
+    rois[:, 1:4] = rng.rand(K, 3) * np.array([32, 32, 8]) * 4
+    rois[:, 4:7] = 4 + rng.rand(K, 3) * np.array([60, 30, 20])
+    rois[:, 7] = rng.rand(K) * 180
+    r = torch.from_numpy(rois).to(dev)
+    g = torch.from_numpy(rng.randn(K, 64, 6, 8, 4).astype(np.float32)).to(dev)
+    grads = []
+    for mode in ("dense", "sparse"):
+        feats = t.features.detach().clone().requires_grad_(True)
+        tt = scn.SparseConvNetTensor(feats, t.metadata, t.spatial_size)
+        if mode == "dense":
+            dense = scn.SparseToDense(3, 64)(tt, batch_size=1)
+            out = roi_align_rotated_3d_forward(dense, r, 0.25, 6, 8, 4, 2)
+        else:
+            out = roi_align_rotated_3d_sparse(tt, r, 0.25, 6, 8, 4, 2, crop=[32, 32, 8])
+        out.backward(g)
+        grads.append((out.detach().cpu().numpy(), feats.grad.cpu().numpy()))
+    assert rel(grads[0][0], grads[1][0]) < 1e-5
+    assert rel(grads[0][1], grads[1][1]) < 1e-4
+    want = oracle.roi_align_rotated_3d_backward(g.cpu().numpy(), rois, 0.25, 6, 8, 4, 2, (1, 64, 32, 32, 8))
+    assert rel(grads[0][1], want[0][:, loc[:, 0], loc[:, 1], loc[:, 2]].T) < 1e-4
