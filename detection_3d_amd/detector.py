@@ -9,7 +9,8 @@ Dense per-site / per-RoI linear algebra (1x1 convs, fc layers) runs on rocBLAS /
 PyTorch; everything sparse, geometric or combinatorial runs in libd3d_hip.so.
 
 Boxes are plain tensors [n,7] in yx_zb mode (xc, yc, z_bot, dy, dx, dz, yaw) instead of BoxList3D
-objects; fields travel next to them in a small dict.  SEPARATE_CLASSES (3G6c) is not wired yet.
+objects; fields travel next to them in a small dict.  SEPARATE_CLASSES (3G6c) runs the RPN selection / losses
+and the RoI losses / post-processing once per class group (SeperateClassifier).
 """
 import math
 
@@ -23,6 +24,43 @@ from . import sparseconvnet as scn
 from . import training as T
 from .config import class_to_label
 from .roi_align_rotated_3d import roi_align_rotated_3d_sparse
+
+
+class SeperateClassifier(object):
+    """Class grouping of modeling/seperate_classifier.py:7-55 (3G6c): group 0 = the classes that were not
+    separated (with the real background column 0); every separated group g >= 1 gets its own background column
+    num_classes + g - 1 followed by its (sorted) classes."""
+
+    def __init__(self, separate_classes_id, num_input_classes):
+        groups = [sorted(g) for g in separate_classes_id]
+        self.need_seperate = len(groups) > 0
+        self.num_input_classes = num_input_classes
+        flat = [c for g in groups for c in g]
+        assert 0 not in flat
+        self.grouped_classes = [[c for c in range(num_input_classes) if c not in flat]]
+        for i, g in enumerate(groups):
+            self.grouped_classes.append([num_input_classes + i] + g)
+        self.group_num = len(self.grouped_classes)
+        self.total_classes = num_input_classes + self.group_num - 1
+        self.class_nums = [len(g) for g in self.grouped_classes]
+
+    def group_targets(self, targets):
+        """-> per group {"bbox3d", "labels"} with labels renumbered inside the group (:268-297)."""
+        out = []
+        for classes in self.grouped_classes:
+            lab = targets["labels"]
+            sel, new = [], []
+            for i, c in enumerate(classes):
+                ids = torch.nonzero(lab == c).view(-1)
+                sel.append(ids)
+                new.append(torch.full_like(ids, i))
+            sel, new = torch.cat(sel), torch.cat(new)
+            out.append({"bbox3d": targets["bbox3d"][sel], "labels": new})
+        return out
+
+    def org_label(self, gi, group_labels):
+        lut = torch.tensor(self.grouped_classes[gi], dtype=torch.int64, device=group_labels.device)
+        return lut[group_labels]
 
 
 def build_backbone(cfg):
@@ -123,6 +161,7 @@ class RPNModule(nn.Module):
         self.nms_aug_thickness = list(rpn.NMS_AUG_THICKNESS_Y_Z)
         self.add_gt_proposals = rpn.ADD_GT_PROPOSALS
         self.loss_evaluator = T.RPNLoss(cfg)
+        self.sep = SeperateClassifier(cfg.MODEL.SEPARATE_CLASSES_ID, len(cfg.INPUT.CLASSES))
 
     @torch.no_grad()
     def select_proposals(self, objectness, box_regression, anchors, train):
@@ -142,6 +181,8 @@ class RPNModule(nn.Module):
         with torch.no_grad():
             anchors = torch.cat(self.anchor_generator(features_sparse), 0)
         assert objectness.shape[0] == box_regression.shape[0] == anchors.shape[0]
+        if self.sep.need_seperate and self.head.seperate_rpn > 1:
+            return self._forward_grouped(anchors, objectness, box_regression, targets)
         proposals, scores = self.select_proposals(objectness.detach(), box_regression.detach(), anchors,
                                                   self.training)
         if not self.training:
@@ -152,6 +193,27 @@ class RPNModule(nn.Module):
             scores = torch.cat([scores, torch.ones(gt.shape[0], device=scores.device)], 0)
         loss_obj, loss_reg = self.loss_evaluator(anchors, objectness.reshape(-1), box_regression, gt)
         return proposals, scores, {"loss_objectness": loss_obj, "loss_rpn_box_reg": loss_reg}
+
+    def _forward_grouped(self, anchors, objectness, box_regression, targets):
+        """seperate_rpn_selector / seperate_rpn_loss_evaluator (seperate_classifier.py:58-95): one proposal set
+        and one loss pair per class group; proposals carry their group id (`sep_id`)."""
+        props, scores, sep_ids, losses = [], [], [], {}
+        tg = self.sep.group_targets(targets) if self.training else [None] * self.sep.group_num
+        for gi in range(self.sep.group_num):
+            obj_g, reg_g = objectness[:, gi], box_regression[:, 7 * gi:7 * gi + 7]
+            p, sc = self.select_proposals(obj_g.detach(), reg_g.detach().contiguous(), anchors, self.training)
+            if self.training:
+                gt = tg[gi]["bbox3d"]
+                if self.add_gt_proposals and gt.shape[0]:
+                    p = torch.cat([p, gt], 0)
+                    sc = torch.cat([sc, torch.ones(gt.shape[0], device=sc.device)], 0)
+                lo, lr = self.loss_evaluator(anchors, obj_g, reg_g, gt)
+                losses[f"loss_objectness_{gi}"], losses[f"loss_rpn_box_reg_{gi}"] = lo, lr
+            props.append(p)
+            scores.append(sc)
+            sep_ids.append(torch.full((p.shape[0],), gi, dtype=torch.int64, device=p.device))
+        out = (torch.cat(props), torch.cat(scores), torch.cat(sep_ids))
+        return out + (losses,) if self.training else out
 
 
 # ----------------------------------------------------------------------------------------------
@@ -307,8 +369,44 @@ class ROIBoxHead3D(nn.Module):
         self.post_processor = PostProcessor(cfg)
 
         self.loss_evaluator = T.ROILoss(cfg)
+        self.sep = SeperateClassifier(cfg.MODEL.SEPARATE_CLASSES_ID, len(cfg.INPUT.CLASSES))
 
-    def forward(self, roi_features, proposals, targets=None):
+    def _forward_grouped(self, roi_features, proposals, sep_id, targets):
+        """seperate_subsample / roi_cross_entropy_seperated / roi_box_loss_seperated / post_processor
+        (seperate_classifier.py:111-176,299-321)."""
+        sep = self.sep
+        if self.training:
+            tg = sep.group_targets(targets)
+            ps, ls, rs, ids = [], [], [], []
+            for gi in range(sep.group_num):
+                p, l, r = self.loss_evaluator.subsample(proposals[sep_id == gi], tg[gi]["bbox3d"], tg[gi]["labels"])
+                ps.append(p); ls.append(l); rs.append(r)
+                ids.append(torch.full((p.shape[0],), gi, dtype=torch.int64, device=p.device))
+            proposals, labels, reg_targets, sep_id = torch.cat(ps), torch.cat(ls), torch.cat(rs), torch.cat(ids)
+        x = self.feature_extractor(roi_features, proposals)
+        logits, reg = self.predictor(x)
+        assert logits.shape[1] == sep.total_classes
+        n = logits.shape[0]
+        out = {} if self.training else []
+        for gi in range(sep.group_num):
+            idx = torch.nonzero(sep_id == gi).view(-1)
+            cols = torch.tensor(sep.grouped_classes[gi], device=logits.device)
+            lg = logits[idx][:, cols]
+            rg = reg.view(n, -1, 7)[:, cols, :].reshape(n, -1)[idx]
+            if self.training:
+                c, b = self.loss_evaluator(lg, rg, proposals[idx], labels[idx], reg_targets[idx])
+                out[f"loss_classifier_roi_{gi}"], out[f"loss_box_reg_roi_{gi}"] = c, b
+            else:
+                res = self.post_processor(lg, rg.contiguous(), proposals[idx])
+                res["labels"] = sep.org_label(gi, res["labels"])
+                out.append(res)
+        if self.training:
+            return out
+        return {k: torch.cat([r[k] for r in out]) for k in ("bbox3d", "scores", "labels")}
+
+    def forward(self, roi_features, proposals, targets=None, sep_id=None):
+        if sep_id is not None:
+            return self._forward_grouped(roi_features, proposals, sep_id, targets)
         if self.training:                                                        # box_head.py:96-149
             proposals, labels, reg_targets = self.loss_evaluator.subsample(proposals, targets["bbox3d"],
                                                                            targets["labels"])
@@ -331,8 +429,6 @@ class SparseRCNN(nn.Module):
 
     def __init__(self, cfg):
         super().__init__()
-        if len(cfg.MODEL.SEPARATE_CLASSES):
-            raise NotImplementedError("SEPARATE_CLASSES (3G6c) grouping is a 'next' row (SURVEY.md 8f rank 4)")
         self.cfg = cfg
         self.backbone = build_backbone(cfg)
         self.rpn = RPNModule(cfg)
@@ -345,10 +441,11 @@ class SparseRCNN(nn.Module):
             if targets is None:
                 raise ValueError("In training mode, targets should be passed")
             rpn_features, roi_features = self.backbone(points)
-            proposals, _, rpn_losses = self.rpn(rpn_features, targets)
-            proposals = proposals.clone()
+            out = self.rpn(rpn_features, targets)
+            proposals, rpn_losses = out[0].clone(), out[-1]
+            sep_id = out[2] if len(out) == 4 else None
             proposals[:, 3:6] = torch.clamp(proposals[:, 3:6], min=0.001)
-            losses = dict(self.roi_heads.box(roi_features, proposals, targets))
+            losses = dict(self.roi_heads.box(roi_features, proposals, targets, sep_id=sep_id))
             losses.update(rpn_losses)
             return losses
         with torch.no_grad():
@@ -356,10 +453,11 @@ class SparseRCNN(nn.Module):
 
     def _forward_eval(self, points, return_intermediates=False):
         rpn_features, roi_features = self.backbone(points)
-        proposals, objectness = self.rpn(rpn_features)
-        proposals = proposals.clone()
+        out = self.rpn(rpn_features)
+        proposals, objectness = out[0].clone(), out[1]
+        sep_id = out[2] if len(out) == 3 else None
         proposals[:, 3:6] = torch.clamp(proposals[:, 3:6], min=0.001)           # BoxList3D.clamp_size
-        result = self.roi_heads.box(roi_features, proposals)
+        result = self.roi_heads.box(roi_features, proposals, sep_id=sep_id)
         if return_intermediates:
             return result, {"rpn_features": rpn_features, "roi_features": roi_features,
                             "proposals": proposals, "objectness": objectness}

@@ -70,3 +70,19 @@ def test_checkpoint_key_names_and_shapes():
     m = build_detection_model(get_cfg("4c_Fpn432"))
     missing = m.load_state_dict({k[len("module."):]: v for k, v in ck.items()}, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
+
+
+def test_seperate_classifier_groups():
+    from detection_3d_amd.detector import SeperateClassifier
+    g = get_cfg("3G6c_Fpn4321")
+    sep = SeperateClassifier(g.MODEL.SEPARATE_CLASSES_ID, len(g.INPUT.CLASSES))
+    assert sep.grouped_classes == [[0, 2, 3], [6, 1], [7, 4, 5]]          # seperate_classifier.py:20-36
+    assert sep.total_classes == 8 and sep.class_nums == [3, 2, 3]
+    t = {"bbox3d": torch.arange(42, dtype=torch.float32).view(6, 7), "labels": torch.tensor([1, 2, 5, 3, 4, 1])}
+    tg = sep.group_targets(t)
+    assert tg[0]["labels"].tolist() == [1, 2] and tg[1]["labels"].tolist() == [1, 1] and tg[2]["labels"].tolist() == [1, 2]
+    assert sep.org_label(2, torch.tensor([1, 2])).tolist() == [4, 5]
+    from detection_3d_amd.detector import build_detection_model
+    m = build_detection_model(g)
+    assert tuple(m.state_dict()["rpn.head.cls_logits.weight"].shape) == (12, 128, 1, 1)
+    assert tuple(m.state_dict()["roi_heads.box.predictor.bbox_pred.weight"].shape) == (56, 512)

@@ -40,6 +40,33 @@ def test_label_generation_against_oracle_iou(dev):
     assert (labels == 1).sum().item() >= targets["bbox3d"].shape[0] // 2
 
 
+def test_3g6c_grouped_train_and_eval(dev):
+    """configs/3G6c: three class groups, each with its own RPN column, proposal budget, background column."""
+    from detection_3d_amd import training as T
+    from detection_3d_amd.synthetic import make_targets
+    cfg, model, coords, feats, targets = _setup(dev, "3G6c_Fpn4321")
+    b, l = make_targets(5)
+    l = l.copy()
+    l[-4:] = [4, 5, 4, 5]                                        # some floor / ceiling boxes
+    b[-4:, 3:6] = [[6.0, 8.0, 0.1]] * 4
+    targets = {"bbox3d": torch.from_numpy(b).to(dev), "labels": torch.from_numpy(l).to(dev)}
+    sep = model.rpn.sep
+    assert sep.grouped_classes == [[0, 2, 3], [6, 1], [7, 4, 5]] and sep.total_classes == 8
+    tg = sep.group_targets(targets)
+    assert [int(t["labels"].max()) for t in tg] == [2, 1, 2]
+    opt = T.make_optimizer(cfg, model)
+    losses = model([coords, feats], targets)
+    assert len(losses) == 12 and all(torch.isfinite(v) for v in losses.values()), losses
+    opt.zero_grad()
+    sum(losses.values()).backward()
+    assert model.rpn.head.cls_logits.weight.grad.abs().sum() > 0
+    opt.step()
+    model.eval()
+    res = model([coords, feats])
+    assert res["bbox3d"].shape[0] <= 3 * cfg.MODEL.ROI_HEADS.DETECTIONS_PER_IMG + 3
+    assert set(res["labels"].unique().tolist()).issubset({1, 2, 3, 4, 5})
+
+
 @pytest.mark.parametrize("name", ["4c_Fpn432", "6c_Fpn4321"])
 def test_train_steps(dev, name):
     from detection_3d_amd import training as T
