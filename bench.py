@@ -141,7 +141,10 @@ def main():
                 "launches_per_step": d["calls"] / args.steps, "avg_launch_us": round(per_launch_ms * 1e3, 1),
                 "algorithmic_gflop_per_launch": round(d["flops"] / d["calls"] / 1e9, 3),
                 "compulsory_GBps": round(gbs, 1), "compulsory_frac_of_hbm": round(gbs / HBM_PEAK_GBS, 4),
-                "all_sparse_conv_ms_per_step": round(conv_ms, 3)}
+                "all_sparse_conv_ms_per_step": round(conv_ms, 3),
+                "families": [{"kernel": f"{k[0]} fv={k[1]} {k[2]}->{k[3]}", "ms_per_step": round(v["ms"] / args.steps, 3),
+                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
+                             for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:6]]}
         out = {
             "metric": "buildings/sec inference, 4c_fpn432", "value": round(world * args.steps / dt_max, 3),
             "unit": "buildings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

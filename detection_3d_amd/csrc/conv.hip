@@ -138,9 +138,27 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
     }
   };
 
+  // B fragments (packed weights) of one (offset, Cin tile) step; with PREB they are fetched one step
+  // ahead as well, so that the L2 latency hides under the previous step's MFMAs (small Cin tiles only:
+  // the register cost is NT * CT/8 float4)
+  constexpr bool PREB = (CT <= 64);
+  constexpr int NQ = CT / 8;
+  f32x4 bcur[PREB ? NQ * NT : 1], bnext[PREB ? NQ * NT : 1];
+  auto load_b = [&](f32x4 *dst, int k, int ct) {
+    const float *wk = wp + ((size_t)(k * (CP / 4) + ct * (CT / 4)) * COUT + colbase) * 4;
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++)
+        dst[q * NT + nt] = *(const f32x4 *)(wk + ((size_t)(2 * q + h) * COUT + nt * 32 + r) * 4);
+  };
+
   int k = mask ? __builtin_ctz(mask) : -1;
   int ct = 0;
-  if (k >= 0) issue_gather(k, 0);
+  if (k >= 0) {
+    issue_gather(k, 0);
+    if constexpr (PREB) load_b(bcur, k, 0);
+  }
   while (k >= 0) {
     commit_gather();
     block_sync();
@@ -151,16 +169,23 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
       mask &= mask - 1;
       nk = mask ? __builtin_ctz(mask) : -1;
     }
-    if (nk >= 0) issue_gather(nk, nct);  // loads fly while the matrix cores work
+    if (nk >= 0) {
+      issue_gather(nk, nct);  // loads fly while the matrix cores work
+      if constexpr (PREB) load_b(bnext, nk, nct);
+    }
     // ---- 32 x (NT*32) += A[32 x CT] * W[k][CT x cols] ----
     const float *wk = wp + ((size_t)(k * (CP / 4) + ct * (CT / 4)) * COUT + colbase) * 4;
 #pragma unroll
-    for (int q = 0; q < CT / 8; q++) {
+    for (int q = 0; q < NQ; q++) {
       const f32x4 a = *(const f32x4 *)(As + r * LDA + q * 8 + h * 4);
       f32x4 b[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; nt++)
-        b[nt] = *(const f32x4 *)(wk + ((size_t)(2 * q + h) * COUT + nt * 32 + r) * 4);
+      for (int nt = 0; nt < NT; nt++) {
+        if constexpr (PREB)
+          b[nt] = bcur[q * NT + nt];
+        else
+          b[nt] = *(const f32x4 *)(wk + ((size_t)(2 * q + h) * COUT + nt * 32 + r) * 4);
+      }
 #pragma unroll
       for (int nt = 0; nt < NT; nt++) {
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[nt][0], acc[nt], 0, 0, 0);
@@ -170,6 +195,10 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
       }
     }
     block_sync();
+    if constexpr (PREB) {
+#pragma unroll
+      for (int i = 0; i < NQ * NT; i++) bcur[i] = bnext[i];
+    }
     k = nk;
     ct = nct;
   }

@@ -123,7 +123,7 @@ namespace d3d {
 int scan_exclusive_i32(const int32_t *in, int32_t *out, int n, int32_t *total_dev, Arena &scratch,
                        hipStream_t s);
 int sort_pairs_u32(const uint32_t *keys_in, uint32_t *keys_out, const int32_t *vals_in,
-                   int32_t *vals_out, int n, int end_bit, Arena &scratch, hipStream_t s);
+                   int32_t *vals_out, int n, int end_bit, Arena &scratch, hipStream_t s, bool descending);
 int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan, hipStream_t s,
                   uint32_t *mask_in);
 int plan_rules(d3d_meta *m, Plan &p, hipStream_t s, long *out);

@@ -110,9 +110,17 @@ int scan_exclusive_i32(const int32_t *in, int32_t *out, int n, int32_t *total_de
 }
 
 int sort_pairs_u32(const uint32_t *keys_in, uint32_t *keys_out, const int32_t *vals_in,
-                   int32_t *vals_out, int n, int end_bit, Arena &scratch, hipStream_t s) {
+                   int32_t *vals_out, int n, int end_bit, Arena &scratch, hipStream_t s, bool descending) {
   if (n <= 0) return D3D_OK;
   size_t tmp_bytes = 0;
+  if (descending) {
+    D3D_HIP_CHECK(rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out,
+                                                 (size_t)n, 0u, (unsigned)end_bit, s));
+    D3D_ALLOC(tmp, char, scratch, tmp_bytes);
+    D3D_HIP_CHECK(rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out,
+                                                 (size_t)n, 0u, (unsigned)end_bit, s));
+    return D3D_OK;
+  }
   D3D_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out,
                                           (size_t)n, 0u, (unsigned)end_bit, s));
   D3D_ALLOC(tmp, char, scratch, tmp_bytes);
@@ -121,6 +129,15 @@ int sort_pairs_u32(const uint32_t *keys_in, uint32_t *keys_out, const int32_t *v
   return D3D_OK;
 }
 
+// sort key of a row: (number of offsets << K) | offset mask -- rows with equal masks stay together and
+// blocks come out ordered by weight; sorted descending so that the heaviest blocks are dispatched first
+__global__ void k_sort_key(const uint32_t *__restrict__ mask, uint32_t *__restrict__ key, int32_t *iota, int n, int K) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t m = mask[i];
+  key[i] = K <= 27 ? (((uint32_t)__popc(m) << K) | m) : m;
+  iota[i] = i;
+}
 __global__ void k_iota(int32_t *p, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = i;
@@ -373,10 +390,11 @@ int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan
     }
     hipLaunchKernelGGL(k_row_mask, grid1d(n_rows), dim3(256), 0, s, nbr, n_rows, K, mask, plan.n_rules_dev);
   }
-  D3D_ALLOC(mask_sorted, uint32_t, A, n_rows);
+  D3D_ALLOC(key, uint32_t, A, n_rows);
+  D3D_ALLOC(key_sorted, uint32_t, A, n_rows);
   D3D_ALLOC(iota, int32_t, A, n_rows);
-  hipLaunchKernelGGL(k_iota, grid1d(n_rows), dim3(256), 0, s, iota, n_rows);
-  int rc = sort_pairs_u32(mask, mask_sorted, iota, rows, n_rows, K, A, s);
+  hipLaunchKernelGGL(k_sort_key, grid1d(n_rows), dim3(256), 0, s, mask, key, iota, n_rows, K);
+  int rc = sort_pairs_u32(key, key_sorted, iota, rows, n_rows, K <= 27 ? K + 5 : K, A, s, true);
   if (rc) return rc;
   if (npos > n_rows) hipLaunchKernelGGL(k_pad_rows, grid1d(npos - n_rows), dim3(256), 0, s, rows, n_rows, npos);
   hipLaunchKernelGGL(k_plan_transpose, grid1d((long)npos * K), dim3(256), 0, s, nbr, rows, npos, K, nbrT);
@@ -684,7 +702,7 @@ int d3d_input_layer_build(d3d_meta *m, const int64_t *coords, int n, int ncols, 
     if (rc) return rc;
     int bits = 1;
     while ((1L << bits) < n_active) bits++;
-    rc = sort_pairs_u32(psite, psite_sorted, iota, in_idx, n, bits, A, s);
+    rc = sort_pairs_u32(psite, psite_sorted, iota, in_idx, n, bits, A, s, false);
     if (rc) return rc;
     D3D_LAUNCH_CHECK();
     A.used = mark;
