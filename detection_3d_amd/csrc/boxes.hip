@@ -318,15 +318,18 @@ __global__ void k_nms_prep(const float *__restrict__ boxes, int n, NmsBox *__res
   r.area = quad_area_f64(r.q.p);
   rec[i] = r;
 }
-// 256 threads per 64 x 64 tile: wave w decides rows 16w..16w+15, lanes = candidate boxes j.
-// Two early-outs that cannot change the decision:
-//  * z intervals do not overlap  -> iou_z <= 0 (or NaN) -> gate `iou3d > 0` is false;
-//  * BEV circumscribed circles are disjoint, or the rectangles are separated along one of their edge
-//    normals (both with a margin of ~1e-3 of the box size, far above fp32 rounding of metre-sized
-//    boxes) -> no corner lies inside the other box and no edges cross -> area 0 -> gate false.
-__global__ __launch_bounds__(256) void k_nms_mask(const NmsBox *__restrict__ rec, int n, int ncb,
-                                                  float thresh,
-                                                  unsigned long long *__restrict__ mask) {
+// Suppression masks in two passes so that the expensive geometry runs with full lanes:
+//  k_nms_pairs  -- 256 threads per 64 x 64 tile (wave w: rows 16w..16w+15, lanes = candidate boxes j):
+//                  cheap exact early-outs, survivors appended to a pair list (wave64 ballot + one atomic
+//                  per wave).  The early-outs cannot change the decision:
+//                   * z intervals do not overlap -> iou_z <= 0 (or NaN) -> gate `iou3d > 0` is false;
+//                   * BEV circumscribed circles disjoint, or rectangles separated along an edge normal (margin
+//                     ~1e-3 of the box size, far above fp32 rounding of metre-sized boxes) -> no corner inside
+//                     the other box, no edges cross -> area 0 -> gate false.
+//  k_nms_eval   -- one thread per listed pair: gate (fp32 IoU of nms_gpu.py x z IoU) and fp64 polygon IoU
+//                  >= thresh; sets bit j of word [i][j/64] (atomicOr, order independent).
+__global__ __launch_bounds__(256) void k_nms_pairs(const NmsBox *__restrict__ rec, int n, int2 *__restrict__ pairs,
+                                                   unsigned int *__restrict__ n_pairs) {
   const int rt = blockIdx.y, ct = blockIdx.x;
   if (ct < rt) return;
   __shared__ NmsBox srow[64];
@@ -339,49 +342,71 @@ __global__ __launch_bounds__(256) void k_nms_mask(const NmsBox *__restrict__ rec
   const int nrow = min(64, n - rt * 64);
   for (int ii = wave * 16; ii < min(nrow, wave * 16 + 16); ii++) {
     const int i = rt * 64 + ii;
-    bool sup = false;
+    bool cand = false;
     if (j < n && j > i) {
       const NmsBox &rb = srow[ii];
       const float overlap = fminf(cb.z1, rb.z1) - fmaxf(cb.z0, rb.z0);
       const float dx = cb.raw[0] - rb.raw[0], dy = cb.raw[1] - rb.raw[1];
       const float rr = (cb.radius + rb.radius) * 1.001f + 1e-4f;
-      if (overlap > 0.f && dx * dx + dy * dy <= rr * rr &&
-          !quads_separated(rb.q.p, cb.q.p, 1e-3f * (1.f + cb.radius + rb.radius))) {
-        // gate = boxes_iou_3d(dets, dets)[i, j] > 0 (nms_cpu.py:35, spconv nms.h)
-        float v = iou_eval(cb.q, cb.d0, cb.d1, rb.q, rb.d0, rb.d1, -1);
-        bool same = true;
-#pragma unroll
-        for (int d = 0; d < 5; d++) same = same && (fabsf(rb.raw[d] - cb.raw[d]) < (float)1e-6);
-        if (same) v = 1.f;
-        const float common = fmaxf(cb.z1, rb.z1) - fminf(cb.z0, rb.z0);
-        v = v * (overlap / common);
-        if (v > 0.0f) {
-          const double ia = quad_inter_f64(rb.q.p, cb.q.p);
-          if (ia > 0) {
-            const double ua = rb.area + cb.area - ia;
-            sup = ua > 0 && ia / ua >= (double)thresh;
-          }
-        }
-      }
+      cand = overlap > 0.f && dx * dx + dy * dy <= rr * rr &&
+             !quads_separated(rb.q.p, cb.q.p, 1e-3f * (1.f + cb.radius + rb.radius));
     }
-    const unsigned long long w = __ballot(sup);
-    if (lane == 0) mask[(size_t)i * ncb + ct] = w;
+    const unsigned long long bal = __ballot(cand);
+    if (bal) {
+      unsigned int base = 0;
+      if (lane == 0) base = atomicAdd(n_pairs, (unsigned int)__popcll(bal));
+      base = __shfl(base, 0, 64);
+      if (cand) pairs[base + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2(i, j);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_nms_eval(const NmsBox *__restrict__ rec, const int2 *__restrict__ pairs,
+                                                  const unsigned int *__restrict__ n_pairs, int ncb, float thresh,
+                                                  unsigned long long *__restrict__ mask) {
+  const unsigned int total = *n_pairs;
+  for (unsigned int p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
+    const int2 ij = pairs[p];
+    const NmsBox rb = rec[ij.x], cb = rec[ij.y];
+    // gate = boxes_iou_3d(dets, dets)[i, j] > 0 (nms_cpu.py:35, spconv nms.h)
+    float v = iou_eval(cb.q, cb.d0, cb.d1, rb.q, rb.d0, rb.d1, -1);
+    bool same = true;
+#pragma unroll
+    for (int d = 0; d < 5; d++) same = same && (fabsf(rb.raw[d] - cb.raw[d]) < (float)1e-6);
+    if (same) v = 1.f;
+    const float overlap = fminf(cb.z1, rb.z1) - fmaxf(cb.z0, rb.z0);
+    const float common = fmaxf(cb.z1, rb.z1) - fminf(cb.z0, rb.z0);
+    v = v * (overlap / common);
+    if (!(v > 0.0f)) continue;
+    const double ia = quad_inter_f64(rb.q.p, cb.q.p);
+    if (!(ia > 0)) continue;
+    const double ua = rb.area + cb.area - ia;
+    if (ua > 0 && ia / ua >= (double)thresh)
+      atomicOr(&mask[(size_t)ij.x * ncb + (ij.y >> 6)], 1ull << (ij.y & 63));
   }
 }
 // Greedy sweep by ONE wave: lane w owns word w of the "removed" bit vector.  Per 64-box chunk the
-// intra-chunk chain is resolved on the diagonal words with readlane; the chunk's 64 mask rows are
-// loaded unconditionally (independent loads, pipelined) and OR-ed in for the kept boxes.
+// intra-chunk chain is resolved on the diagonal words with v_readlane; the chunk's 64 mask rows are
+// loaded unconditionally in one batch (independent loads) and OR-ed in for the kept boxes; the next
+// chunk's diagonal word is fetched one chunk ahead.
 __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long *__restrict__ mask, int n,
                                                   int ncb, int32_t *__restrict__ keep,
                                                   int32_t *__restrict__ n_keep) {
   const int lane = threadIdx.x;
   unsigned long long removed = 0;  // word `lane`
   int cnt = 0;
+  unsigned long long diag_next = (lane < min(64, n)) ? mask[(size_t)lane * ncb] : 0ull;
   for (int c = 0; c < ncb; c++) {
     const int base = c * 64;
     const int nrow = min(64, n - base);
-    unsigned long long diag = 0;
-    if (lane < nrow) diag = mask[(size_t)(base + lane) * ncb + c];
+    const unsigned long long diag = diag_next;
+    if (c + 1 < ncb) {
+      const int nr2 = min(64, n - base - 64);
+      diag_next = (lane < nr2) ? mask[(size_t)(base + 64 + lane) * ncb + c + 1] : 0ull;
+    }
+    const bool mine = lane > c && lane < ncb;  // words left of the diagonal are never read again
+    unsigned long long w[64];
+#pragma unroll
+    for (int b = 0; b < 64; b++) w[b] = (mine && b < nrow) ? mask[(size_t)(base + b) * ncb + lane] : 0ull;
     unsigned long long alive = ~__shfl(removed, c, 64);
     if (nrow < 64) alive &= (1ull << nrow) - 1ull;
     unsigned long long kept = 0;
@@ -395,19 +420,9 @@ __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long *__re
         alive &= ~d;
       }
     }
-    const bool mine = lane > c && lane < ncb;  // words left of the diagonal are never read again
-#pragma unroll 1
-    for (int b0 = 0; b0 < 64; b0 += 16) {
-      unsigned long long w[16];
 #pragma unroll
-      for (int u = 0; u < 16; u++) {
-        const int b = b0 + u;
-        w[u] = (mine && b < nrow) ? mask[(size_t)(base + b) * ncb + lane] : 0ull;
-      }
-#pragma unroll
-      for (int u = 0; u < 16; u++)
-        if ((kept >> (b0 + u)) & 1ull) removed |= w[u];
-    }
+    for (int b = 0; b < 64; b++)
+      if ((kept >> b) & 1ull) removed |= w[b];
     unsigned long long k = kept;
     while (k) {
       const int b = __builtin_ctzll(k);
@@ -484,7 +499,7 @@ int d3d_boxes_iou_3d(const float *targets, int M, const float *anchors, int N, c
 
 size_t d3d_nms_scratch_bytes(int n) {
   size_t ncb = ((size_t)n + 63) / 64;
-  return (size_t)n * ncb * 8 + (size_t)n * sizeof(NmsBox) + 1024;
+  return (size_t)n * ncb * 8 + (size_t)n * sizeof(NmsBox) + ((size_t)n * n / 2 + 64) * sizeof(int2) + 2048;
 }
 
 int d3d_rotate_nms_3d_sorted(const float *boxes, int n, float thresh, int32_t *keep, int32_t *n_keep,
@@ -498,10 +513,18 @@ int d3d_rotate_nms_3d_sorted(const float *boxes, int n, float thresh, int32_t *k
   }
   D3D_REQUIRE(boxes && keep && scratch && scratch_bytes >= d3d_nms_scratch_bytes(n), "rotate_nms_3d: bad buffers");
   const int ncb = (n + 63) / 64;
-  unsigned long long *mask = (unsigned long long *)scratch;
-  NmsBox *rec = (NmsBox *)((char *)scratch + (((size_t)n * ncb * 8 + 255) & ~size_t(255)));
+  char *base = (char *)scratch;
+  unsigned long long *mask = (unsigned long long *)base;
+  size_t off = ((size_t)n * ncb * 8 + 255) & ~size_t(255);
+  unsigned int *n_pairs = (unsigned int *)(base + off);
+  off += 256;
+  NmsBox *rec = (NmsBox *)(base + off);
+  off = (off + (size_t)n * sizeof(NmsBox) + 255) & ~size_t(255);
+  int2 *pairs = (int2 *)(base + off);
+  D3D_HIP_CHECK(hipMemsetAsync(mask, 0, (size_t)n * ncb * 8 + 256 + 256, s));   // masks + pair counter
   hipLaunchKernelGGL(k_nms_prep, dim3((n + 127) / 128), dim3(128), 0, s, boxes, n, rec);
-  hipLaunchKernelGGL(k_nms_mask, dim3(ncb, ncb), dim3(256), 0, s, rec, n, ncb, thresh, mask);
+  hipLaunchKernelGGL(k_nms_pairs, dim3(ncb, ncb), dim3(256), 0, s, rec, n, pairs, n_pairs);
+  hipLaunchKernelGGL(k_nms_eval, dim3(512), dim3(256), 0, s, rec, pairs, n_pairs, ncb, thresh, mask);
   hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(64), 0, s, mask, n, ncb, keep, n_keep);
   D3D_LAUNCH_CHECK();
   return D3D_OK;

@@ -87,8 +87,7 @@ struct Plan {
   int K = 0;
   int n_rows = 0;
   int n_blk = 0;
-  long n_rules = 0;                           // -1: still on the device (n_rules_dev)
-  unsigned long long *n_rules_dev = nullptr;
+  long n_rules = 0;                           // -1: not counted yet (plan_rules counts on demand)
   int32_t *rows = nullptr;
   int32_t *nbrT = nullptr;
   uint32_t *blkmask = nullptr;
@@ -139,14 +138,22 @@ __device__ __forceinline__ uint64_t pack_key(int b, int x, int y, int z) {
   return ((uint64_t)(uint16_t)b << 48) | ((uint64_t)(uint16_t)x << 32) |
          ((uint64_t)(uint16_t)y << 16) | (uint64_t)(uint16_t)z;
 }
+// Locality-preserving slot choice: the 2x2x2 cell block a voxel belongs to is hashed to a group of 8
+// consecutive 16-B slots (one 128-B line) and the voxel's position inside the block picks the slot, so
+// the 27 neighbour probes of a site touch <= 8 lines (and the 8 trilinear corners of a sample <= 8,
+// usually 1-2) instead of one random line each.  Collisions step by whole groups.
+static constexpr uint64_t kLowBits = 0x0000000100010001ULL;  // bit 0 of x, y, z in the packed key
 __device__ __forceinline__ uint32_t hash_key(uint64_t k) {
+  const uint32_t intra = (uint32_t)((k >> 32) & 1) << 2 | (uint32_t)((k >> 16) & 1) << 1 | (uint32_t)(k & 1);
+  k &= ~kLowBits;
   k ^= k >> 33;
   k *= 0xff51afd7ed558ccdULL;
   k ^= k >> 33;
   k *= 0xc4ceb9fe1a85ec53ULL;
   k ^= k >> 33;
-  return (uint32_t)k;
+  return ((uint32_t)k << 3) | intra;
 }
+static constexpr uint32_t kProbeStep = 8;
 // returns the slot holding `key` (inserting it if absent)
 __device__ __forceinline__ int hash_insert(HashEntry *tab, int cap, uint64_t key) {
   uint32_t slot = hash_key(key) & (uint32_t)(cap - 1);
@@ -154,7 +161,7 @@ __device__ __forceinline__ int hash_insert(HashEntry *tab, int cap, uint64_t key
     unsigned long long prev = atomicCAS((unsigned long long *)&tab[slot].key,
                                         (unsigned long long)kEmptyKey, (unsigned long long)key);
     if (prev == kEmptyKey || prev == key) return (int)slot;
-    slot = (slot + 1) & (uint32_t)(cap - 1);
+    slot = (slot + kProbeStep) & (uint32_t)(cap - 1);
   }
 }
 // returns the site id stored for `key`, or -1 (one 16-B load per probed slot)
@@ -166,7 +173,7 @@ __device__ __forceinline__ int hash_find(const HashEntry *__restrict__ tab, int 
     const uint64_t k = ((uint64_t)e[1] << 32) | e[0];
     if (k == key) return (int)e[2];
     if (k == kEmptyKey) return -1;
-    slot = (slot + 1) & (uint32_t)(cap - 1);
+    slot = (slot + kProbeStep) & (uint32_t)(cap - 1);
   }
 }
 

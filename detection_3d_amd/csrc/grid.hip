@@ -282,51 +282,55 @@ __global__ void k_conv_fill(const int32_t *__restrict__ loc, long n_entries, Con
   nbr_dec[(size_t)i * K + off] = oid;
 }
 
-// a4. Submanifold neighbour probes (SubmanifoldConvolutionRules.h:13-45), one thread per output
-// site: the K probes are independent loads, the row's offset mask and the rule count come for free.
+// a4. Submanifold neighbour probes (SubmanifoldConvolutionRules.h:13-45).  A 256-thread block owns 64
+// output sites; its 64*K probes are spread over the threads (independent loads in flight), the [site][k]
+// table is written coalesced, and the per-site offset masks are assembled in LDS.
+static constexpr int kNbrSites = 64;
 __global__ __launch_bounds__(256) void k_subm_nbr(const int32_t *__restrict__ loc, int n, int fx, int fy,
                                                   int fz, const HashEntry *__restrict__ tab, int cap,
-                                                  int32_t *__restrict__ nbr, uint32_t *__restrict__ mask,
-                                                  unsigned long long *n_rules) {
+                                                  int32_t *__restrict__ nbr, uint32_t *__restrict__ mask) {
+  __shared__ uint32_t smask[kNbrSites];
+  __shared__ int32_t sloc[kNbrSites * 4];
   const int K = fx * fy * fz;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t m = 0;
-  if (i < n) {
-    const int32_t *p = loc + (size_t)i * 4;
-    const int px = p[0] - fx / 2, py = p[1] - fy / 2, pz = p[2] - fz / 2, pb = p[3];
-    int k = 0;
-    for (int dx = 0; dx < fx; dx++)
-      for (int dy = 0; dy < fy; dy++)
-#pragma unroll 3
-        for (int dz = 0; dz < fz; dz++, k++) {
-          const int x = px + dx, y = py + dy, z = pz + dz;
-          int v = -1;
-          if (x >= 0 && y >= 0 && z >= 0) v = hash_find(tab, cap, pack_key(pb, x, y, z));
-          nbr[(size_t)i * K + k] = v;
-          m |= (v >= 0 ? 1u : 0u) << k;
-        }
-    mask[i] = m;
+  const int s0 = blockIdx.x * kNbrSites;
+  const int ns = min(kNbrSites, n - s0);
+  if (threadIdx.x < kNbrSites) smask[threadIdx.x] = 0;
+  for (int e = threadIdx.x; e < ns * 4; e += 256) sloc[e] = loc[(size_t)s0 * 4 + e];
+  __syncthreads();
+  for (int e = threadIdx.x; e < ns * K; e += 256) {
+    const int ls = e / K, k = e % K;
+    const int dz = k % fz, dy = (k / fz) % fy, dx = k / (fz * fy);
+    const int x = sloc[ls * 4] - fx / 2 + dx, y = sloc[ls * 4 + 1] - fy / 2 + dy, z = sloc[ls * 4 + 2] - fz / 2 + dz;
+    int v = -1;
+    if (x >= 0 && y >= 0 && z >= 0) v = hash_find(tab, cap, pack_key(sloc[ls * 4 + 3], x, y, z));
+    nbr[(size_t)s0 * K + e] = v;
+    if (v >= 0) atomicOr(&smask[ls], 1u << k);
   }
-  int c = __popc(m);
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(n_rules, (unsigned long long)c);
+  __syncthreads();
+  if (threadIdx.x < ns) mask[s0 + threadIdx.x] = smask[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------
 // Plan finalisation: per-row offset masks, sort rows by mask, transpose, block masks.
-__global__ void k_row_mask(const int32_t *__restrict__ nbr, int n, int K, uint32_t *mask,
-                           unsigned long long *n_rules) {
+__global__ void k_row_mask(const int32_t *__restrict__ nbr, int n, int K, uint32_t *mask) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
   uint32_t m = 0;
-  if (i < n)
-    for (int k = 0; k < K; k++) m |= (nbr[(size_t)i * K + k] >= 0 ? 1u : 0u) << k;
-  if (i < n) mask[i] = m;
-  // wave-level popcount reduction, one atomic per wave
-  int c = __popc(m);
+  for (int k = 0; k < K; k++) m |= (nbr[(size_t)i * K + k] >= 0 ? 1u : 0u) << k;
+  mask[i] = m;
+}
+// number of rules of a plan = valid entries of nbrT; only run when somebody asks for the MAC count
+__global__ __launch_bounds__(256) void k_count_rules(const int32_t *__restrict__ nbrT, long total,
+                                                     unsigned long long *n_rules) {
+  __shared__ int wsum[4];
+  int c = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    c += nbrT[i] >= 0;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(n_rules, (unsigned long long)c);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(n_rules, (unsigned long long)(wsum[0] + wsum[1] + wsum[2] + wsum[3]));
 }
 __global__ void k_plan_transpose(const int32_t *__restrict__ nbr, const int32_t *__restrict__ rows,
                                  int npos, int K, int32_t *__restrict__ nbrT) {
@@ -375,11 +379,6 @@ int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan
   plan.blkmask = blkmask;
   plan.n_rules = n_rows == 0 ? 0 : -1;
   if (n_rows == 0) return D3D_OK;
-  if (!plan.n_rules_dev) {
-    D3D_ALLOC(cnt, unsigned long long, A, 1);
-    plan.n_rules_dev = cnt;
-    D3D_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), s));
-  }
   size_t mark = A.used;
   uint32_t *mask = mask_in;
   if (!mask) {
@@ -388,7 +387,7 @@ int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan
       set_error("metadata arena exhausted while finalising a rulebook");
       return D3D_ERR_NOMEM;
     }
-    hipLaunchKernelGGL(k_row_mask, grid1d(n_rows), dim3(256), 0, s, nbr, n_rows, K, mask, plan.n_rules_dev);
+    hipLaunchKernelGGL(k_row_mask, grid1d(n_rows), dim3(256), 0, s, nbr, n_rows, K, mask);
   }
   D3D_ALLOC(key, uint32_t, A, n_rows);
   D3D_ALLOC(key_sorted, uint32_t, A, n_rows);
@@ -408,7 +407,16 @@ int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan
 // reads the rule count back (one stream sync) the first time it is asked for
 int plan_rules(d3d_meta *m, Plan &p, hipStream_t s, long *out) {
   if (p.n_rules < 0) {
-    D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[0], p.n_rules_dev, sizeof(long), hipMemcpyDeviceToHost, s));
+    Arena &A = m->arena;
+    size_t mark = A.used;
+    D3D_ALLOC(cnt, unsigned long long, A, 1);
+    D3D_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), s));
+    const long total = (long)p.n_blk * 32 * p.K;
+    hipLaunchKernelGGL(k_count_rules, dim3((unsigned)std::min<long>(1024, (total + 255) / 256)), dim3(256), 0, s,
+                       p.nbrT, total, cnt);
+    D3D_LAUNCH_CHECK();
+    A.used = mark;
+    D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[0], cnt, sizeof(long), hipMemcpyDeviceToHost, s));
     D3D_HIP_CHECK(hipStreamSynchronize(s));
     p.n_rules = m->host_words[0];
   }
@@ -813,12 +821,9 @@ int d3d_subm_prepare(d3d_meta *m, const int *size, const int *filt, void *stream
     } else {
       int32_t *nbr = (int32_t *)(A.base + ((A.cap - raw_bytes) & ~size_t(255)));
       uint32_t *mask = (uint32_t *)((char *)nbr - (((size_t)g->n * 4 + 511) & ~size_t(255)));
-      D3D_ALLOC(cnt, unsigned long long, A, 1);
-      p.n_rules_dev = cnt;
-      D3D_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), s));
       if (g->n)
-        hipLaunchKernelGGL(k_subm_nbr, grid1d(g->n), dim3(256), 0, s, g->loc, g->n, filt[0], filt[1], filt[2],
-                           g->tab, g->cap, nbr, mask, cnt);
+        hipLaunchKernelGGL(k_subm_nbr, grid1d(g->n, kNbrSites), dim3(256), 0, s, g->loc, g->n, filt[0], filt[1], filt[2],
+                           g->tab, g->cap, nbr, mask);
       D3D_LAUNCH_CHECK();
       int rc;
       {
