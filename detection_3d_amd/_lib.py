@@ -13,6 +13,14 @@ _lib = None
 c_int_p = ctypes.POINTER(ctypes.c_int)
 vp = ctypes.c_void_p
 
+
+class BnPrologue(ctypes.Structure):
+    """d3d_bn_prologue (include/d3d_hip.h): device pointers of the producer's BatchNorm."""
+    _fields_ = [("mean", vp), ("invstd", vp), ("weight", vp), ("bias", vp), ("leakiness", ctypes.c_float)]
+
+
+bn_p = ctypes.POINTER(BnPrologue)
+
 _SIGS = {
     "d3d_last_error": (ctypes.c_char_p, []),
     "d3d_abi_version": (ctypes.c_int, []),
@@ -39,11 +47,14 @@ _SIGS = {
     "d3d_packed_weight_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "d3d_pack_conv_weight": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "d3d_subm_conv_forward": (ctypes.c_int, [vp, c_int_p, c_int_p, vp, ctypes.c_int, vp, ctypes.c_int, vp,
-                                             vp, vp, ctypes.POINTER(ctypes.c_double)]),
+                                             vp, vp, ctypes.POINTER(ctypes.c_double), bn_p]),
     "d3d_conv_forward": (ctypes.c_int, [vp, c_int_p, c_int_p, c_int_p, c_int_p, vp, ctypes.c_int, vp,
-                                        ctypes.c_int, vp, vp, ctypes.POINTER(ctypes.c_double)]),
+                                        ctypes.c_int, vp, vp, ctypes.POINTER(ctypes.c_double), bn_p]),
     "d3d_deconv_forward": (ctypes.c_int, [vp, c_int_p, c_int_p, c_int_p, c_int_p, vp, ctypes.c_int, vp,
-                                          ctypes.c_int, vp, vp, vp, ctypes.POINTER(ctypes.c_double)]),
+                                          ctypes.c_int, vp, vp, vp, ctypes.POINTER(ctypes.c_double), bn_p]),
+    "d3d_bn_apply": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_float, vp]),
+    "d3d_bn_batch_invstd": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, vp, vp, vp,
+                                           ctypes.c_size_t, vp]),
     "d3d_pack_conv_weight_transposed": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                        vp, vp]),
     "d3d_subm_conv_backward": (ctypes.c_int, [vp, c_int_p, c_int_p, vp, ctypes.c_int, vp, ctypes.c_int, vp, vp,
@@ -83,7 +94,7 @@ _SIGS = {
     "d3d_rotate_iou_eval": (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp]),
     "d3d_boxes_iou_3d": (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                         ctypes.c_int, ctypes.c_int, vp, vp]),
-    "d3d_rotate_nms_3d_sorted": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_float, vp, vp, vp,
+    "d3d_rotate_nms_3d_sorted": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, vp, vp, vp,
                                                 ctypes.c_size_t, vp]),
     "d3d_nms_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "d3d_box_decode": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.c_float,

@@ -69,7 +69,7 @@ def boxes_iou_3d(targets_bbox3d, anchors_bbox3d, aug_thickness=None, criterion=-
 _NMS_SCRATCH = {}
 
 
-def _nms_sorted(boxes_sorted, thresh):
+def _nms_sorted(boxes_sorted, thresh, max_keep=0):
     n = boxes_sorted.shape[0]
     dev = boxes_sorted.device
     nbytes = lib().d3d_nms_scratch_bytes(n)
@@ -79,8 +79,8 @@ def _nms_sorted(boxes_sorted, thresh):
         _NMS_SCRATCH[dev.index] = buf
     keep = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     nk = torch.zeros(1, dtype=torch.int32, device=dev)
-    check(lib().d3d_rotate_nms_3d_sorted(ptr(boxes_sorted), n, float(thresh), ptr(keep), ptr(nk), ptr(buf),
-                                         buf.numel(), stream_of()))
+    check(lib().d3d_rotate_nms_3d_sorted(ptr(boxes_sorted), n, float(thresh), int(max_keep or 0), ptr(keep), ptr(nk),
+                                         ptr(buf), buf.numel(), stream_of()))
     return keep, nk
 
 
@@ -95,7 +95,7 @@ def rotate_nms_3d(rbboxes, scores, pre_max_size=None, post_max_size=None, iou_th
         raise D3DError("rotate_nms_3d: more than 4096 candidates; pass pre_max_size (reference uses 2000)")
     # descending score order; ties -> lower index first (stable), same rule as the oracle
     order = torch.sort(scores, descending=True, stable=True)[1][:k]
-    keep, nk = _nms_sorted(rbboxes[order].contiguous(), iou_threshold)
+    keep, nk = _nms_sorted(rbboxes[order].contiguous(), iou_threshold, post_max_size)
     n_keep = int(nk.item())
     if post_max_size is not None:
         n_keep = min(n_keep, post_max_size)

@@ -69,6 +69,9 @@ __global__ __launch_bounds__(256) void k_bn_finish(const double *__restrict__ pa
   if (mode == 0) {
     o0[c] = (float)mean;
     o1[c] = (float)(m2 / (rows - 1));
+  } else if (mode == 2) {  // eval with batch statistics: invstd from the unbiased variance (float, then + eps)
+    o0[c] = (float)mean;
+    o1[c] = powf((float)(m2 / (rows - 1)) + eps, -0.5f);
   } else {
     o0[c] = (float)mean;
     running_mean[c] = momentum * running_mean[c] + (1 - momentum) * (float)mean;
@@ -162,6 +165,18 @@ int d3d_bn_batch_stats(const float *in, int rows, int planes, float *mean, float
   return D3D_OK;
 }
 
+int d3d_bn_batch_invstd(const float *in, int rows, int planes, float eps, float *mean, float *invstd,
+                        void *scratch, size_t scratch_bytes, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(in && mean && invstd && rows > 0, "bn_batch_invstd: bad arguments");
+  int nblk;
+  int rc = run_partial(in, rows, planes, scratch, scratch_bytes, s, &nblk);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_bn_finish, dim3((planes + 31) / 32), dim3(256), 0, s, (const double *)scratch, nblk, rows, planes, 2, mean, invstd, nullptr, nullptr, eps, 0.f);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
 int d3d_bn_forward(const float *in, float *out, int rows, int planes, float *save_mean,
                    float *save_invstd, float *running_mean, float *running_var, const float *weight,
                    const float *bias, float eps, float momentum, int train, float leakiness,
@@ -180,6 +195,17 @@ int d3d_bn_forward(const float *in, float *out, int rows, int planes, float *sav
   }
   size_t total = (size_t)rows * planes;
   hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)((total / 4 + 256) / 256)), dim3(256), 0, s, in, out, total, planes, save_mean, save_invstd, weight, bias, leakiness);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+int d3d_bn_apply(const float *in, float *out, int rows, int planes, const float *mean, const float *invstd,
+                 const float *weight, const float *bias, float leakiness, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (rows == 0) return D3D_OK;
+  D3D_REQUIRE(in && out && mean && invstd && planes > 0 && rows > 0, "bn_apply: bad arguments");
+  size_t total = (size_t)rows * planes;
+  hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)((total / 4 + 256) / 256)), dim3(256), 0, s, in, out, total, planes, mean, invstd, weight, bias, leakiness);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }

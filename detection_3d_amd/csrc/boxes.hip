@@ -389,13 +389,13 @@ __global__ __launch_bounds__(256) void k_nms_eval(const NmsBox *__restrict__ rec
 // loaded unconditionally in one batch (independent loads) and OR-ed in for the kept boxes; the next
 // chunk's diagonal word is fetched one chunk ahead.
 __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long *__restrict__ mask, int n,
-                                                  int ncb, int32_t *__restrict__ keep,
+                                                  int ncb, int max_keep, int32_t *__restrict__ keep,
                                                   int32_t *__restrict__ n_keep) {
   const int lane = threadIdx.x;
   unsigned long long removed = 0;  // word `lane`
   int cnt = 0;
   unsigned long long diag_next = (lane < min(64, n)) ? mask[(size_t)lane * ncb] : 0ull;
-  for (int c = 0; c < ncb; c++) {
+  for (int c = 0; c < ncb && cnt < max_keep; c++) {   // the caller keeps at most max_keep survivors
     const int base = c * 64;
     const int nrow = min(64, n - base);
     const unsigned long long diag = diag_next;
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long *__re
       cnt++;
     }
   }
-  if (lane == 0) *n_keep = cnt;
+  if (lane == 0) *n_keep = min(cnt, max_keep);  // the last chunk may overshoot the cap
 }
 
 // a14. BoxCoder3D.decode
@@ -502,8 +502,8 @@ size_t d3d_nms_scratch_bytes(int n) {
   return (size_t)n * ncb * 8 + (size_t)n * sizeof(NmsBox) + ((size_t)n * n / 2 + 64) * sizeof(int2) + 2048;
 }
 
-int d3d_rotate_nms_3d_sorted(const float *boxes, int n, float thresh, int32_t *keep, int32_t *n_keep,
-                             void *scratch, size_t scratch_bytes, void *stream) {
+int d3d_rotate_nms_3d_sorted(const float *boxes, int n, float thresh, int max_keep, int32_t *keep,
+                             int32_t *n_keep, void *scratch, size_t scratch_bytes, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   D3D_REQUIRE(n >= 0 && n <= 4096, "rotate_nms_3d: n=%d out of range (<= 4096)", n);
   D3D_REQUIRE(n_keep, "rotate_nms_3d: null n_keep");
@@ -525,7 +525,7 @@ int d3d_rotate_nms_3d_sorted(const float *boxes, int n, float thresh, int32_t *k
   hipLaunchKernelGGL(k_nms_prep, dim3((n + 127) / 128), dim3(128), 0, s, boxes, n, rec);
   hipLaunchKernelGGL(k_nms_pairs, dim3(ncb, ncb), dim3(256), 0, s, rec, n, pairs, n_pairs);
   hipLaunchKernelGGL(k_nms_eval, dim3(512), dim3(256), 0, s, rec, pairs, n_pairs, ncb, thresh, mask);
-  hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(64), 0, s, mask, n, ncb, keep, n_keep);
+  hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(64), 0, s, mask, n, ncb, max_keep > 0 ? max_keep : n, keep, n_keep);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }

@@ -18,6 +18,11 @@ namespace d3d {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+struct BnPre {  // fused BatchNorm(+leaky ReLU) prologue; mean == nullptr: none
+  const float *mean, *invstd, *weight, *bias;
+  float leak;
+};
+
 __device__ __forceinline__ void wave_lds_sync() {
   // LDS operations of one wave execute in issue order; this only stops the compiler from
   // moving LDS accesses of different lanes across the hand-off point.
@@ -59,7 +64,7 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
     const float *__restrict__ in, int cin, const float *__restrict__ wp,
     const int32_t *__restrict__ nbrT, int npos, const int32_t *__restrict__ rows,
     const uint32_t *__restrict__ blkmask, int n_blk, const float *__restrict__ residual,
-    float *__restrict__ out, int n_split, float *__restrict__ partial) {
+    float *__restrict__ out, int n_split, float *__restrict__ partial, BnPre pre) {
   constexpr int WPBLK = COUT / 32 / NT;
   static_assert(WPBLK == 1 || BPW == 1, "row blocks sharing a workgroup must be single-wave");
   constexpr int TPB = WPBLK * 64;  // threads working on one row block
@@ -107,7 +112,29 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
   const int32_t *nb = nbrT + blk * 32;
   // register-staged gather of (offset k, Cin tile ct): issued one step ahead of its use
   f32x4 stage[NIT];
+  // optional fused BatchNorm + leaky ReLU of the producer layer (y = leaky(x*w + b), applied to real rows
+  // only: a missing neighbour contributes zeros, as a zero row of the normalised tensor would not);
+  // this thread always gathers the same 4 channels of a Cin tile, so w and b are fetched once
+  f32x4 bnw[NCT], bnb[NCT];
+#pragma unroll
+  for (int t = 0; t < NCT; t++) {
+    bnw[t] = {1.f, 1.f, 1.f, 1.f};
+    bnb[t] = {0.f, 0.f, 0.f, 0.f};
+    if (pre.mean) {
+      const int c = t * CT + gc4 * 4;
+      const f32x4 is = *(const f32x4 *)(pre.invstd + c), mu = *(const f32x4 *)(pre.mean + c);
+      const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 ga = pre.weight ? *(const f32x4 *)(pre.weight + c) : one;
+      const f32x4 be = pre.bias ? *(const f32x4 *)(pre.bias + c) : zero;
+      bnw[t] = is * ga;
+      bnb[t] = -mu * bnw[t] + be;
+    }
+  }
+  uint32_t stage_real = 0;  // bit it: stage[it] holds a real row (BatchNorm applies)
+  int stage_ct = 0;
   auto issue_gather = [&](int k, int ct) {
+    stage_real = 0;
+    stage_ct = ct;
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
       const int row = it * RPP + grow;
@@ -118,6 +145,7 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
           const float *p = in + (size_t)s * cin + ct * CT + gc4 * 4;
           if (vec) {
             v = *(const f32x4 *)p;
+            stage_real |= 1u << it;
           } else {
             const int c = ct * CT + gc4 * 4;
             if (c + 0 < cin) v[0] = p[0];
@@ -131,10 +159,18 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
     }
   };
   auto commit_gather = [&]() {
+    // the normalisation runs here, after the previous step's MFMAs, so that the gather loads stay in flight
+    const f32x4 bw = stage_ct == 0 ? bnw[0] : bnw[NCT - 1], bb = stage_ct == 0 ? bnb[0] : bnb[NCT - 1];
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
       const int row = it * RPP + grow;
-      if (row < 32) *(f32x4 *)(As + row * LDA + gc4 * 4) = stage[it];
+      f32x4 v = stage[it];
+      if (pre.mean && ((stage_real >> it) & 1u)) {
+        v = v * bw + bb;
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = v[j] * ((v[j] > 0) ? 1.f : pre.leak);
+      }
+      if (row < 32) *(f32x4 *)(As + row * LDA + gc4 * 4) = v;
     }
   };
 
@@ -249,7 +285,7 @@ static constexpr int kSplitTargetWaves = 2048;  // below this many waves the lau
 
 template <int CT, int NCT, int COUT, int NT, int BPW>
 static int launch_t(d3d_meta *m, const Plan &p, const float *in, int cin, const float *wp,
-                    const float *residual, float *out, hipStream_t s) {
+                    const float *residual, float *out, hipStream_t s, BnPre pre) {
   constexpr int WPBLK = COUT / 32 / NT;
   constexpr int threads = BPW * WPBLK * 64;
   const int npos = p.n_blk * 32;
@@ -267,7 +303,7 @@ static int launch_t(d3d_meta *m, const Plan &p, const float *in, int cin, const 
   }
   dim3 grid((p.n_blk + BPW - 1) / BPW, n_split);
   hipLaunchKernelGGL((k_conv<CT, NCT, COUT, NT, BPW>), grid, dim3(threads), 0, s, in, cin, wp, p.nbrT, npos,
-                     p.rows, p.blkmask, p.n_blk, residual, out, n_split, partial);
+                     p.rows, p.blkmask, p.n_blk, residual, out, n_split, partial, pre);
   if (n_split > 1) {
     const long total = (long)npos * (COUT / 4);
     hipLaunchKernelGGL(k_conv_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, partial, n_split,
@@ -280,27 +316,32 @@ static int launch_t(d3d_meta *m, const Plan &p, const float *in, int cin, const 
 
 template <int CT, int NCT>
 static int launch_c(d3d_meta *m, const Plan &p, const float *in, int cin, const float *wp, int cout,
-                    const float *residual, float *out, hipStream_t s) {
+                    const float *residual, float *out, hipStream_t s, BnPre pre) {
   switch (cout) {
-    case 32: return launch_t<CT, NCT, 32, 1, 4>(m, p, in, cin, wp, residual, out, s);    // 4 independent waves
-    case 64: return launch_t<CT, NCT, 64, 1, 1>(m, p, in, cin, wp, residual, out, s);    // 2 waves / block
-    case 128: return launch_t<CT, NCT, 128, 1, 1>(m, p, in, cin, wp, residual, out, s);  // 4 waves / block
-    case 256: return launch_t<CT, NCT, 256, 1, 1>(m, p, in, cin, wp, residual, out, s);  // 8 waves / block
+    case 32: return launch_t<CT, NCT, 32, 1, 4>(m, p, in, cin, wp, residual, out, s, pre);    // 4 independent waves
+    case 64: return launch_t<CT, NCT, 64, 1, 1>(m, p, in, cin, wp, residual, out, s, pre);    // 2 waves / block
+    case 128: return launch_t<CT, NCT, 128, 1, 1>(m, p, in, cin, wp, residual, out, s, pre);  // 4 waves / block
+    case 256: return launch_t<CT, NCT, 256, 1, 1>(m, p, in, cin, wp, residual, out, s, pre);  // 8 waves / block
   }
   set_error("convolution: Cout=%d not supported (32, 64, 128, 256)", cout);
   return D3D_ERR_UNSUPPORTED;
 }
 
 int launch_conv(d3d_meta *m, const Plan &p, const float *in, int cin, const float *packed_w, int cout,
-                const float *residual, float *out, hipStream_t s) {
+                const float *residual, float *out, hipStream_t s, const d3d_bn_prologue *bn) {
   if (p.n_rows == 0) return D3D_OK;
   D3D_REQUIRE(in && packed_w && out, "convolution: null pointer");
+  BnPre pre = {nullptr, nullptr, nullptr, nullptr, 0.f};
+  if (bn && bn->mean) {
+    D3D_REQUIRE(bn->invstd && cin % 8 == 0 && padded_cin(cin) == cin, "fused BatchNorm prologue needs Cin in {32,64,128,256}");
+    pre = {bn->mean, bn->invstd, bn->weight, bn->bias, bn->leakiness};
+  }
   switch (padded_cin(cin)) {
-    case 16: return launch_c<16, 1>(m, p, in, cin, packed_w, cout, residual, out, s);
-    case 32: return launch_c<32, 1>(m, p, in, cin, packed_w, cout, residual, out, s);
-    case 64: return launch_c<64, 1>(m, p, in, cin, packed_w, cout, residual, out, s);
-    case 128: return launch_c<128, 1>(m, p, in, cin, packed_w, cout, residual, out, s);
-    case 256: return launch_c<128, 2>(m, p, in, cin, packed_w, cout, residual, out, s);
+    case 16: return launch_c<16, 1>(m, p, in, cin, packed_w, cout, residual, out, s, pre);
+    case 32: return launch_c<32, 1>(m, p, in, cin, packed_w, cout, residual, out, s, pre);
+    case 64: return launch_c<64, 1>(m, p, in, cin, packed_w, cout, residual, out, s, pre);
+    case 128: return launch_c<128, 1>(m, p, in, cin, packed_w, cout, residual, out, s, pre);
+    case 256: return launch_c<128, 2>(m, p, in, cin, packed_w, cout, residual, out, s, pre);
   }
   set_error("convolution: Cin=%d not supported (<= 256)", cin);
   return D3D_ERR_UNSUPPORTED;
@@ -330,7 +371,7 @@ int d3d_pack_conv_weight(const float *w, int fv, int cin, int cout, float *packe
 
 int d3d_subm_conv_forward(d3d_meta *m, const int *size, const int *filt, const float *in, int cin,
                           const float *packed_w, int cout, const float *residual, float *out,
-                          void *stream, double *macs_host) {
+                          void *stream, double *macs_host, const d3d_bn_prologue *bn) {
   hipStream_t s = (hipStream_t)stream;
   D3D_REQUIRE(m && size && filt, "null argument");
   int rc = d3d_subm_prepare(m, size, filt, stream, nullptr);
@@ -342,12 +383,12 @@ int d3d_subm_conv_forward(d3d_meta *m, const int *size, const int *filt, const f
     if (rc) return rc;
     *macs_host = (double)nr * cin * cout;
   }
-  return launch_conv(m, *p, in, cin, packed_w, cout, residual, out, s);
+  return launch_conv(m, *p, in, cin, packed_w, cout, residual, out, s, bn);
 }
 
 int d3d_conv_forward(d3d_meta *m, const int *in_size, const int *out_size, const int *filt,
                      const int *stride, const float *in, int cin, const float *packed_w, int cout,
-                     float *out, void *stream, double *macs_host) {
+                     float *out, void *stream, double *macs_host, const d3d_bn_prologue *bn) {
   hipStream_t s = (hipStream_t)stream;
   D3D_REQUIRE(m && in_size && out_size && filt && stride, "null argument");
   int rc = d3d_conv_prepare(m, in_size, out_size, filt, stride, stream, nullptr, nullptr);
@@ -359,14 +400,15 @@ int d3d_conv_forward(d3d_meta *m, const int *in_size, const int *out_size, const
     if (rc) return rc;
     *macs_host = (double)nr * cin * cout;
   }
-  return launch_conv(m, *p, in, cin, packed_w, cout, nullptr, out, s);
+  return launch_conv(m, *p, in, cin, packed_w, cout, nullptr, out, s, bn);
 }
 
 // Deconvolution: in = coarse features, out = fine features; reuses the strided rulebook of the
 // matching convolution with the roles swapped (SCN/CPU/Deconvolution.cpp:17,33-37).
 int d3d_deconv_forward(d3d_meta *m, const int *in_size, const int *out_size, const int *filt,
                        const int *stride, const float *in, int cin, const float *packed_w, int cout,
-                       const float *residual, float *out, void *stream, double *macs_host) {
+                       const float *residual, float *out, void *stream, double *macs_host,
+                       const d3d_bn_prologue *bn) {
   hipStream_t s = (hipStream_t)stream;
   D3D_REQUIRE(m && in_size && out_size && filt && stride, "null argument");
   const Plan *p = nullptr;
@@ -378,7 +420,7 @@ int d3d_deconv_forward(d3d_meta *m, const int *in_size, const int *out_size, con
     if (rc) return rc;
     *macs_host = (double)nr * cin * cout;
   }
-  return launch_conv(m, *p, in, cin, packed_w, cout, residual, out, s);
+  return launch_conv(m, *p, in, cin, packed_w, cout, residual, out, s, bn);
 }
 
 }  // extern "C"

@@ -132,7 +132,7 @@ int get_deconv_plan(d3d_meta *m, const int *fine_size, const int *filt, const in
 
 // conv.hip
 int launch_conv(d3d_meta *m, const Plan &p, const float *in, int cin, const float *packed_w, int cout,
-                const float *residual, float *out, hipStream_t s);
+                const float *residual, float *out, hipStream_t s, const d3d_bn_prologue *bn = nullptr);
 
 __device__ __forceinline__ uint64_t pack_key(int b, int x, int y, int z) {
   return ((uint64_t)(uint16_t)b << 48) | ((uint64_t)(uint16_t)x << 32) |

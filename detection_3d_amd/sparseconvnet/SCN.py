@@ -205,6 +205,40 @@ def InputLayer_updateOutput(m, spatial_size, input_coords, input_features, outpu
     check(lib().d3d_input_layer_forward(m._h, ptr(feats), planes, ptr(output_features), stream_of()))
 
 
+def _bn_struct(bn):
+    """bn = (mean, invstd, weight, bias, leakiness) device tensors -> d3d_bn_prologue (kept alive by caller)."""
+    if bn is None:
+        return None
+    mean, invstd, weight, bias, leak = bn
+    return ctypes.byref(_lib.BnPrologue(mean.data_ptr(), invstd.data_ptr(),
+                                        weight.data_ptr() if weight is not None else None,
+                                        bias.data_ptr() if bias is not None else None, float(leak)))
+
+
+def batch_mean_invstd(features, eps):
+    """mean(0) and powf(var_unbiased(0) + eps, -0.5) in one pass pair (eval path of batchNormalization.py:51-56
+    followed by SCN/CPU/BatchNormalization.cpp:40-44)."""
+    require_gpu(features)
+    rows, planes = features.shape
+    mean = torch.empty(planes, dtype=torch.float32, device=features.device)
+    invstd = torch.empty_like(mean)
+    nbytes = lib().d3d_bn_scratch_bytes(planes)
+    scratch = _scratch(features.device, nbytes)
+    check(lib().d3d_bn_batch_invstd(ptr(features), rows, planes, float(eps), ptr(mean), ptr(invstd), ptr(scratch),
+                                    scratch.numel(), stream_of()))
+    return mean, invstd
+
+
+def bn_apply(features, mean, invstd, weight, bias, leakiness):
+    """y = leaky(x * invstd*gamma + (beta - mean*invstd*gamma)) -- the normalisation half of
+    BatchNormalization_updateOutput (SCN/CPU/BatchNormalization.cpp:46-59)."""
+    require_gpu(features)
+    out = torch.empty_like(features)
+    check(lib().d3d_bn_apply(ptr(features), ptr(out), features.shape[0], features.shape[1], ptr(mean), ptr(invstd),
+                             ptr(weight), ptr(bias), float(leakiness), stream_of()))
+    return out
+
+
 def _conv_common(weight, packed):
     fv, groups, cin, cout = weight.shape
     if packed is None:
@@ -213,7 +247,7 @@ def _conv_common(weight, packed):
 
 
 def SubmanifoldConvolution_updateOutput(spatial_size, filter_size, m, input_features,
-                                        output_features, weight, bias, packed=None, residual=None):
+                                        output_features, weight, bias, packed=None, residual=None, bn=None):
     """sparseconvnet.h:99-105; returns the multiply-add count like the reference."""
     require_gpu(input_features, weight)
     if bias is not None and bias.numel():
@@ -229,14 +263,15 @@ def SubmanifoldConvolution_updateOutput(spatial_size, filter_size, m, input_feat
         check(lib().d3d_subm_prepare(m._h, ints(size), ints(filt), stream_of(), None))
         t0 = prof.begin()
     check(lib().d3d_subm_conv_forward(m._h, ints(size), ints(filt), ptr(input_features), cin, ptr(packed),
-                                      cout, ptr(residual), ptr(output_features), stream_of(), want))
+                                      cout, ptr(residual), ptr(output_features), stream_of(), want,
+                                      _bn_struct(bn)))
     if prof is not None:
         prof.end(t0, "subm", fv, cin, cout, n, n, macs.value)
     return macs.value
 
 
 def Convolution_updateOutput(input_size, output_size, filter_size, filter_stride, m, input_features,
-                             output_features, weight, bias, packed=None):
+                             output_features, weight, bias, packed=None, bn=None):
     """sparseconvnet.h:85-91."""
     require_gpu(input_features, weight)
     if bias is not None and bias.numel():
@@ -253,14 +288,14 @@ def Convolution_updateOutput(input_size, output_size, filter_size, filter_stride
     if prof is not None:
         t0 = prof.begin()
     check(lib().d3d_conv_forward(m._h, ints(isz), ints(osz), ints(filt), ints(st), ptr(input_features), cin,
-                                 ptr(packed), cout, ptr(output_features), stream_of(), want))
+                                 ptr(packed), cout, ptr(output_features), stream_of(), want, _bn_struct(bn)))
     if prof is not None:
         prof.end(t0, "conv", fv, cin, cout, input_features.shape[0], n_out.value, macs.value)
     return macs.value
 
 
 def Deconvolution_updateOutput(input_size, output_size, filter_size, filter_stride, m, input_features,
-                               output_features, weight, bias, packed=None, residual=None):
+                               output_features, weight, bias, packed=None, residual=None, bn=None):
     """sparseconvnet.h:147-152: input = coarse, output = fine (rulebook of the matching Convolution)."""
     require_gpu(input_features, weight)
     if bias is not None and bias.numel():
@@ -277,7 +312,7 @@ def Deconvolution_updateOutput(input_size, output_size, filter_size, filter_stri
         t0 = prof.begin()
     check(lib().d3d_deconv_forward(m._h, ints(isz), ints(osz), ints(filt), ints(st), ptr(input_features),
                                    cin, ptr(packed), cout, ptr(residual), ptr(output_features), stream_of(),
-                                   want))
+                                   want, _bn_struct(bn)))
     if prof is not None:
         prof.end(t0, "deconv", fv, cin, cout, input_features.shape[0], n, macs.value)
     return macs.value

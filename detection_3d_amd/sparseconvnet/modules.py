@@ -11,6 +11,9 @@ from torch.nn import Module, Parameter
 from . import SCN
 
 
+FUSE_BN_INTO_CONV = True   # inference only; results are bit-identical to the unfused path
+
+
 def toLongTensor(dimension, x):
     """sparseconvnet/utils.py:11-18."""
     if isinstance(x, torch.Tensor):
@@ -53,6 +56,33 @@ class SparseConvNetTensor(object):
                 f"spatial size={self.spatial_size.tolist()}>>")
 
 
+class _PendingBN(SparseConvNetTensor):
+    """Output of an inference-mode BatchNorm whose affine + activation has not been applied yet: the next
+    convolution fuses it into its gather (d3d_bn_prologue).  Any other consumer touching `.features` gets
+    the materialised tensor."""
+
+    def __init__(self, raw, bn, metadata, spatial_size):
+        self._raw, self.bn, self._mat = raw, bn, None
+        self.metadata, self.spatial_size = metadata, spatial_size
+
+    @property
+    def features(self):
+        if self._mat is None:
+            self._mat = SCN.bn_apply(self._raw, *self.bn)
+        return self._mat
+
+    @features.setter
+    def features(self, v):
+        self._mat = v
+
+
+def _conv_input(input):
+    """(features to read, fused-BN tuple or None)"""
+    if isinstance(input, _PendingBN) and input._mat is None and input._raw.shape[1] in (32, 64, 128, 256):
+        return input._raw, input.bn
+    return input.features, None
+
+
 def _like(inp, features, spatial_size=None):
     return SparseConvNetTensor(features, inp.metadata, inp.spatial_size if spatial_size is None else spatial_size)
 
@@ -77,18 +107,19 @@ class _ConvFn(torch.autograd.Function):
     forward epilogue; its gradient is d_out."""
 
     @staticmethod
-    def forward(ctx, feats, weight, residual, kind, metadata, in_size, out_size, filter_size, filter_stride, packed):
+    def forward(ctx, feats, weight, residual, kind, metadata, in_size, out_size, filter_size, filter_stride, packed,
+                bn=None):
         out = feats.new_empty(0)
         res = None if residual is None else residual.contiguous()
         if kind == 0:
             SCN.SubmanifoldConvolution_updateOutput(in_size, filter_size, metadata, feats, out, weight, None,
-                                                    packed=packed, residual=res)
+                                                    packed=packed, residual=res, bn=bn)
         elif kind == 1:
             SCN.Convolution_updateOutput(in_size, out_size, filter_size, filter_stride, metadata, feats, out, weight,
-                                         None, packed=packed)
+                                         None, packed=packed, bn=bn)
         else:
             SCN.Deconvolution_updateOutput(in_size, out_size, filter_size, filter_stride, metadata, feats, out,
-                                           weight, None, packed=packed, residual=res)
+                                           weight, None, packed=packed, residual=res, bn=bn)
         ctx.save_for_backward(feats, weight)
         ctx.args = (kind, metadata, in_size, out_size, filter_size, filter_stride, residual is not None)
         return out
@@ -110,7 +141,8 @@ class _ConvFn(torch.autograd.Function):
         else:
             SCN.Deconvolution_backward(in_size, out_size, filter_size, filter_stride, metadata, feats, d_in, d_out,
                                        weight, d_w, None, want_d_input=want_in)
-        return (d_in if want_in else None, d_w, d_out if has_res else None, None, None, None, None, None, None, None)
+        return (d_in if want_in else None, d_w, d_out if has_res else None, None, None, None, None, None, None, None,
+                None)
 
 
 class _BatchNormFn(torch.autograd.Function):
@@ -201,11 +233,12 @@ class SubmanifoldConvolution(Module, _PackedWeightMixin):
         self.weight = Parameter(torch.empty(self.filter_volume, groups, nIn // groups, nOut // groups).normal_(0, std))
 
     def forward(self, input, residual=None):
-        assert input.features.nelement() == 0 or input.features.size(1) == self.nIn, (self.nIn, self.nOut)
-        f = _ConvFn.apply(input.features, self.weight, None if residual is None else residual.features, 0,
+        feats, bn = _conv_input(input)
+        assert feats.nelement() == 0 or feats.size(1) == self.nIn, (self.nIn, self.nOut)
+        f = _ConvFn.apply(feats, self.weight, None if residual is None else residual.features, 0,
                           input.metadata, input.spatial_size, input.spatial_size, self.filter_size, None,
-                          self._packed())
-        return _like(input, f)
+                          self._packed(), bn)
+        return SparseConvNetTensor(f, input.metadata, input.spatial_size)
 
     def input_spatial_size(self, out_size):
         return out_size
@@ -225,13 +258,14 @@ class Convolution(Module, _PackedWeightMixin):
         self.weight = Parameter(torch.empty(self.filter_volume, groups, nIn // groups, nOut // groups).normal_(0, std))
 
     def forward(self, input):
-        assert input.features.nelement() == 0 or input.features.size(1) == self.nIn
+        feats, bn = _conv_input(input)
+        assert feats.nelement() == 0 or feats.size(1) == self.nIn
         out_size = (input.spatial_size - self.filter_size) // self.filter_stride + 1
         assert ((out_size - 1) * self.filter_stride + self.filter_size == input.spatial_size).all(), \
             (input.spatial_size, out_size, self.filter_size, self.filter_stride)
-        f = _ConvFn.apply(input.features, self.weight, None, 1, input.metadata, input.spatial_size, out_size,
-                          self.filter_size, self.filter_stride, self._packed())
-        return _like(input, f, out_size)
+        f = _ConvFn.apply(feats, self.weight, None, 1, input.metadata, input.spatial_size, out_size,
+                          self.filter_size, self.filter_stride, self._packed(), bn)
+        return SparseConvNetTensor(f, input.metadata, out_size)
 
     def input_spatial_size(self, out_size):
         return (out_size - 1) * self.filter_stride + self.filter_size
@@ -251,12 +285,13 @@ class Deconvolution(Module, _PackedWeightMixin):
         self.weight = Parameter(torch.empty(self.filter_volume, groups, nIn // groups, nOut // groups).normal_(0, std))
 
     def forward(self, input, residual=None):
-        assert input.features.nelement() == 0 or input.features.size(1) == self.nIn
+        feats, bn = _conv_input(input)
+        assert feats.nelement() == 0 or feats.size(1) == self.nIn
         out_size = (input.spatial_size - 1) * self.filter_stride + self.filter_size
-        f = _ConvFn.apply(input.features, self.weight, None if residual is None else residual.features, 2,
+        f = _ConvFn.apply(feats, self.weight, None if residual is None else residual.features, 2,
                           input.metadata, input.spatial_size, out_size, self.filter_size, self.filter_stride,
-                          self._packed())
-        return _like(input, f, out_size)
+                          self._packed(), bn)
+        return SparseConvNetTensor(f, input.metadata, out_size)
 
     def input_spatial_size(self, out_size):
         return (out_size - self.filter_size) // self.filter_stride + 1
@@ -279,6 +314,13 @@ class BatchNormalization(Module):
     def forward(self, input):
         f = input.features
         assert f.nelement() == 0 or f.size(1) == self.nPlanes, (self.nPlanes, f.shape)
+        if not (self.training or self.track_running_stats) and not torch.is_grad_enabled() and FUSE_BN_INTO_CONV:
+            # inference with batch statistics (batchNormalization.py:53-55): hand (mean, invstd, gamma, beta, leak)
+            # to the consuming convolution instead of writing the normalised tensor
+            mean, invstd = SCN.batch_mean_invstd(f, self.eps)
+            return _PendingBN(f, (mean, invstd, self.weight if self.affine else None,
+                                  self.bias if self.affine else None, self.leakiness), input.metadata,
+                              input.spatial_size)
         if self.training or self.track_running_stats:
             mean, var = self.running_mean, self.running_var
         else:  # batchNormalization.py:53-55: batch statistics stand in for the running ones

@@ -106,16 +106,26 @@ int d3d_pack_conv_weight(const float *w, int filter_volume, int cin, int cout, f
  * bias-free (fpn_net.py builds every conv with bias=False).  `residual` (may be null) is added
  * in the epilogue (fuses sparseconvnet/tables.py AddTable).  *macs_host (may be null)
  * receives rules*Cin*Cout like the reference's return value.                                 */
+/* Optional fusion of the PRODUCER's BatchNormalization (+ leaky ReLU) into the gather of a convolution:
+ * the conv reads the un-normalised rows and applies y = leaky(x * (invstd*weight) + (bias - mean*invstd*weight))
+ * on the fly (same arithmetic as d3d_bn_forward), which removes one full read+write of the tensor.  Host
+ * struct with device pointers; pass NULL (or mean == NULL) for none.                                 */
+typedef struct {
+  const float *mean, *invstd, *weight, *bias; /* [Cin]; weight / bias may be NULL */
+  float leakiness;
+} d3d_bn_prologue;
 int d3d_subm_conv_forward(d3d_meta *m, const int *spatial_size_host, const int *filter_host,
                           const float *in, int cin, const float *packed_w, int cout,
-                          const float *residual, float *out, void *stream, double *macs_host);
+                          const float *residual, float *out, void *stream, double *macs_host,
+                          const d3d_bn_prologue *bn_host);
 int d3d_conv_forward(d3d_meta *m, const int *in_size_host, const int *out_size_host,
                      const int *filter_host, const int *stride_host, const float *in, int cin,
-                     const float *packed_w, int cout, float *out, void *stream, double *macs_host);
+                     const float *packed_w, int cout, float *out, void *stream, double *macs_host,
+                     const d3d_bn_prologue *bn_host);
 int d3d_deconv_forward(d3d_meta *m, const int *in_size_host, const int *out_size_host,
                        const int *filter_host, const int *stride_host, const float *in, int cin,
                        const float *packed_w, int cout, const float *residual, float *out,
-                       void *stream, double *macs_host);
+                       void *stream, double *macs_host, const d3d_bn_prologue *bn_host);
 
 /* a7. Backward (training).  SubmanifoldConvolution_backward / Convolution_backward / Deconvolution_backward
  * (SCN/sparseconvnet.h:92-98,106-111,153-158; SCN/CUDA/Convolution.cu:249-442): d_in is overwritten,
@@ -170,6 +180,14 @@ int d3d_bn_forward(const float *in, float *out, int rows, int planes, float *sav
                    float leakiness, void *scratch, size_t scratch_bytes, void *stream);
 int d3d_bn_batch_stats(const float *in, int rows, int planes, float *mean, float *var_unbiased,
                        void *scratch, size_t scratch_bytes, void *stream);
+/* mean(0) and invstd = powf(var_unbiased(0) + eps, -0.5): what the eval path with track_running_stats=False
+ * feeds the normalisation with; use with d3d_bn_prologue.                                            */
+int d3d_bn_batch_invstd(const float *in, int rows, int planes, float eps, float *mean, float *invstd,
+                        void *scratch, size_t scratch_bytes, void *stream);
+/* the normalisation alone, y = leaky(x * (invstd*gamma) + (beta - mean*invstd*gamma)) (BatchNormalization.cpp:46-59),
+ * for a consumer of a deferred BatchNorm that is not a convolution.                                   */
+int d3d_bn_apply(const float *in, float *out, int rows, int planes, const float *mean, const float *invstd,
+                 const float *weight, const float *bias, float leakiness, void *stream);
 size_t d3d_bn_scratch_bytes(int planes);
 /* sparseconvnet/utils.py:61-66 add_feature_planes / tables.py AddTable: out = a + b. */
 int d3d_add(const float *a, const float *b, float *out, size_t n, void *stream);
@@ -204,8 +222,9 @@ int d3d_boxes_iou_3d(const float *targets, int M, const float *anchors, int N,
 /* a15/a18. rotate_nms_3d_cc (second/core/non_max_suppression/nms_cpu.py:32-44) + spconv's
  * rotate_non_max_suppression_cpu: boxes [n,7] yx_zb ALREADY sorted by descending score
  * (the callers top-k first, box_torch_ops.py:495-499).  keep int32 [n] receives positions in
- * selection order; n_keep (device int32).  scratch >= d3d_nms_scratch_bytes(n).              */
-int d3d_rotate_nms_3d_sorted(const float *boxes, int n, float thresh, int32_t *keep,
+ * selection order; n_keep (device int32).  The sweep may stop once max_keep (> 0) survivors exist: the
+ * callers truncate to post_max_size anyway (box_torch_ops.py:506).  scratch >= d3d_nms_scratch_bytes(n). */
+int d3d_rotate_nms_3d_sorted(const float *boxes, int n, float thresh, int max_keep, int32_t *keep,
                              int32_t *n_keep, void *scratch, size_t scratch_bytes, void *stream);
 size_t d3d_nms_scratch_bytes(int n);
 /* a14. BoxCoder3D.decode (maskrcnn_benchmark/modeling/box_coder_3d.py:38-65). */

@@ -161,3 +161,18 @@ def test_roi_align_dense_and_sparse(dev):
     assert _close(got_d, want, 1e-5)
     assert _close(got_s, want, 1e-5)
     assert np.abs(want).max() > 0.1
+
+
+@pytest.mark.parametrize("cap", [1, 17, 64, 300])
+def test_nms_max_keep_is_prefix_of_full_sweep(dev, cap):
+    """post_max_size stops the greedy sweep early (box_torch_ops.py:511-513 truncates afterwards): the capped
+    result is the first `cap` survivors of the uncapped one."""
+    from detection_3d_amd import box_ops
+    b, s = make_boxes(77, 1500)
+    order = np.argsort(-s, kind="stable")
+    bs = torch.from_numpy(b[order]).to(dev)
+    full, nf = box_ops._nms_sorted(bs, 0.4)
+    part, npart = box_ops._nms_sorted(bs, 0.4, cap)
+    nf, npart = int(nf), int(npart)
+    assert npart == min(cap, nf)
+    assert torch.equal(part[:npart], full[:npart])
