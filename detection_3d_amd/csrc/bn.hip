@@ -4,80 +4,173 @@
 
 namespace d3d {
 
-static constexpr int kStatBlocks = 512;  // partial-sum rows (>= 2 per CU)
+static constexpr int kStatThreads = 1024;
+static constexpr int kStatBlocks = 512;   // row slices (2 workgroups of 16 waves per CU)
+static constexpr int kStatGroup = 16;     // slices per first-level group
+static constexpr int kStatMaxGroups = kStatBlocks / kStatGroup;
+static constexpr size_t kTicketBytes = 256;  // [0] = groups done, [1 + g] = slices of group g done
 
-// partial[b][0..C) = sum, partial[b][C..2C) = sum of squares over the rows of slice b
-__global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x, int rows, int C,
-                                                    double *__restrict__ partial) {
-  extern __shared__ double red[];  // [256][2]
+// sums n rows of src[n][V] column-wise in a fixed order: thread (slice sl, value vi) adds rows sl, sl+SL, ...
+// and slice 0 adds the slices in order; dst[v] receives the result.  All kStatThreads threads must call.
+__device__ __forceinline__ void stat_reduce_rows(const double *__restrict__ src, int n, int V, double *__restrict__ dst,
+                                                 double *red) {
   const int tid = threadIdx.x;
-  const int lanes_per_row = C < 256 ? C : 256;   // threads covering one row
-  const int row_lanes = 256 / lanes_per_row;     // rows handled concurrently (C | 256 assumed if C<256)
-  const int rl = tid / lanes_per_row, cl = tid % lanes_per_row;
-  const int per = (rows + gridDim.x - 1) / gridDim.x;
-  const int r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
-  for (int c = cl; c < C; c += lanes_per_row) {
-    double s = 0, ss = 0;
-    if (rl < row_lanes)
-      for (int r = r0 + rl; r < r1; r += row_lanes) {
-        double v = (double)x[(size_t)r * C + c];
-        s += v;
-        ss += v * v;
-      }
-    red[tid * 2] = s;
-    red[tid * 2 + 1] = ss;
+  const int VP = V < kStatThreads ? V : kStatThreads, SL = kStatThreads / VP;
+  const int sl = tid / VP, vi = tid - sl * VP;
+  for (int vb = 0; vb < V; vb += VP) {
+    const int v = vb + vi;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int b = sl;
+    for (; b + 3 * SL < n; b += 4 * SL) {
+      a0 += src[(size_t)b * V + v];
+      a1 += src[(size_t)(b + SL) * V + v];
+      a2 += src[(size_t)(b + 2 * SL) * V + v];
+      a3 += src[(size_t)(b + 3 * SL) * V + v];
+    }
+    for (; b < n; b += SL) a0 += src[(size_t)b * V + v];
+    double acc = (a0 + a1) + (a2 + a3);
+    red[tid] = acc;
     __syncthreads();
-    if (rl == 0) {
-      for (int j = 1; j < row_lanes; j++) {
-        s += red[(j * lanes_per_row + cl) * 2];
-        ss += red[(j * lanes_per_row + cl) * 2 + 1];
-      }
-      partial[(size_t)blockIdx.x * 2 * C + c] = s;
-      partial[(size_t)blockIdx.x * 2 * C + C + c] = ss;
+    if (sl == 0) {
+      for (int q = 1; q < SL; q++) acc += red[q * VP + vi];
+      dst[v] = acc;
     }
     __syncthreads();
   }
 }
 
-// mode 0: batch_stats -> mean, unbiased var (torch .mean(0)/.var(0), batchNormalization.py:54-55)
-// mode 1: train       -> save_mean, save_invstd, running update (BatchNormalization.cpp:20-38)
-__global__ __launch_bounds__(256) void k_bn_finish(const double *__restrict__ partial, int nblk,
-                                                   int rows, int C, int mode, float *o0, float *o1,
-                                                   float *running_mean, float *running_var,
-                                                   float eps, float momentum) {
-  // block = 32 channels x 8 slices of the partial rows; fixed summation order (deterministic)
-  __shared__ double red[256][2];
-  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
-  double s = 0, ss = 0;
-  if (c < C)
-    for (int b = sl; b < nblk; b += 8) {
-      s += partial[(size_t)b * 2 * C + c];
-      ss += partial[(size_t)b * 2 * C + C + c];
+// Column statistics in ONE launch.  Workgroup b sums slice b of the rows in fp64 (threads = float4 channel
+// groups x concurrent rows, 4 rows in flight per thread) and parks sum / sum-of-squares in partial[b]; the
+// last workgroup of each group of kStatGroup slices to arrive (ticket counter) adds that group's partials,
+// and the last group to finish adds the group sums and writes the statistics.  Every sum has a fixed order,
+// so the result does not depend on which workgroups happen to be last (deterministic, no float atomics).
+//   mode 0: mean, unbiased var   (torch .mean(0)/.var(0), batchNormalization.py:54-55)
+//   mode 1: train -> save_mean, save_invstd (biased), running update (BatchNormalization.cpp:20-38)
+//   mode 2: mean, powf(unbiased var + eps, -0.5)   (eval with batch statistics)
+// HBM-bound: rows * C * 4 bytes read once.  The tickets are zero on entry and are left zero.
+__global__ __launch_bounds__(kStatThreads) void k_bn_stats(const float *__restrict__ x, int rows, int C,
+                                                           unsigned int *tickets, double *partial, double *gpartial,
+                                                           double *total, int mode, float *o0, float *o1,
+                                                           float *running_mean, float *running_var, float eps,
+                                                           float momentum) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  __shared__ double red[4][kStatThreads];
+  __shared__ int flag;
+  const int tid = threadIdx.x;
+  const int C4 = C >> 2;                                    // float4 groups per row (C % 4 == 0)
+  const int LPR = C4 < kStatThreads ? C4 : kStatThreads;    // threads covering one row
+  const int RL = kStatThreads / LPR;                        // rows handled concurrently (LPR | 1024)
+  const int rl = tid / LPR, cl = tid - rl * LPR;
+  const int nblk = gridDim.x, V = 2 * C;
+  const int per = (rows + nblk - 1) / nblk;
+  const int r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
+  for (int g4 = cl; g4 < C4; g4 += LPR) {
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    int r = r0 + rl;
+    for (; r + 3 * RL < r1; r += 4 * RL) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = *(const f32x4 *)(x + (size_t)(r + u * RL) * C + g4 * 4);
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const double d = (double)v[u][j];
+          s[j] += d;
+          ss[j] += d * d;
+        }
     }
-  red[threadIdx.x][0] = s;
-  red[threadIdx.x][1] = ss;
+    for (; r < r1; r += RL) {
+      const f32x4 v = *(const f32x4 *)(x + (size_t)r * C + g4 * 4);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const double d = (double)v[j];
+        s[j] += d;
+        ss[j] += d * d;
+      }
+    }
+    // rows of one channel group live in lanes cl, cl+LPR, ... of every wave: xor-butterfly inside the wave
+    // (both partners compute the same sum), then one LDS entry per wave (or per row lane when LPR >= 64)
+    if (LPR < 64)
+      for (int d = LPR; d < 64; d <<= 1)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          s[j] += __shfl_xor(s[j], d, 64);
+          ss[j] += __shfl_xor(ss[j], d, 64);
+        }
+    const int NE = LPR < 64 ? kStatThreads / 64 : RL;
+    const int e = LPR < 64 ? (tid >> 6) : rl;
+    const bool holder = LPR < 64 ? (tid & 63) < LPR : true;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      double *vals = half ? ss : s;
+      if (holder)
+#pragma unroll
+        for (int j = 0; j < 4; j++) red[j][e * LPR + cl] = vals[j];
+      __syncthreads();
+      if (e == 0 && holder)
+        for (int q = 1; q < NE; q++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) vals[j] += red[j][q * LPR + cl];
+      __syncthreads();
+    }
+    if (e == 0 && holder) {
+      double *pp = partial + (size_t)blockIdx.x * V;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        pp[g4 * 4 + j] = s[j];
+        pp[C + g4 * 4 + j] = ss[j];
+      }
+    }
+  }
+  // ---- level 1: the last slice of a group to arrive adds the group's partials ----
+  const int ngroups = (nblk + kStatGroup - 1) / kStatGroup;
+  const int grp = blockIdx.x / kStatGroup;
+  const int gsize = min(kStatGroup, nblk - grp * kStatGroup);
+  // one agent-scope release / acquire per workgroup (an L2 write-back / invalidate each on a multi-XCD part):
+  // the barrier orders the other threads' stores before thread 0's fence and their loads after it
   __syncthreads();
-  if (sl != 0 || c >= C) return;
-  for (int j = 1; j < 8; j++) {
-    s += red[j * 32 + cl][0];
-    ss += red[j * 32 + cl][1];
+  if (tid == 0) {
+    __threadfence();
+    flag = atomicAdd(&tickets[1 + grp], 1u) == (unsigned)gsize - 1;
+    if (flag) __threadfence();
   }
-  double mean = s / rows;
-  double m2 = ss - mean * mean * rows;  // sum of squared deviations
-  if (m2 < 0) m2 = 0;
-  if (mode == 0) {
-    o0[c] = (float)mean;
-    o1[c] = (float)(m2 / (rows - 1));
-  } else if (mode == 2) {  // eval with batch statistics: invstd from the unbiased variance (float, then + eps)
-    o0[c] = (float)mean;
-    o1[c] = powf((float)(m2 / (rows - 1)) + eps, -0.5f);
-  } else {
-    o0[c] = (float)mean;
-    running_mean[c] = momentum * running_mean[c] + (1 - momentum) * (float)mean;
-    running_var[c] = momentum * running_var[c] + (1 - momentum) * (float)(m2 / (rows - 1));
-    o1[c] = powf((float)(m2 / rows) + eps, -0.5f);
+  __syncthreads();
+  if (!flag) return;
+  double *lvl1 = ngroups == 1 ? total : gpartial + (size_t)grp * V;
+  stat_reduce_rows(partial + (size_t)grp * kStatGroup * V, gsize, V, lvl1, &red[0][0]);
+  if (ngroups > 1) {
+    // ---- level 2: the last group adds the group sums ----
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();
+      flag = atomicAdd(&tickets[0], 1u) == (unsigned)ngroups - 1;
+      if (flag) __threadfence();
+    }
+    __syncthreads();
+    if (!flag) return;
+    stat_reduce_rows(gpartial, ngroups, V, total, &red[0][0]);
   }
+  __syncthreads();  // total[] was written by this workgroup
+  for (int c = tid; c < C; c += kStatThreads) {
+    const double sum = total[c], sq = total[C + c];
+    const double mean = sum / rows;
+    double m2 = sq - mean * mean * rows;  // sum of squared deviations
+    if (m2 < 0) m2 = 0;
+    if (mode == 0) {
+      o0[c] = (float)mean;
+      o1[c] = (float)(m2 / (rows - 1));
+    } else if (mode == 2) {
+      o0[c] = (float)mean;
+      o1[c] = powf((float)(m2 / (rows - 1)) + eps, -0.5f);
+    } else {
+      o0[c] = (float)mean;
+      running_mean[c] = momentum * running_mean[c] + (1 - momentum) * (float)mean;
+      running_var[c] = momentum * running_var[c] + (1 - momentum) * (float)(m2 / (rows - 1));
+      o1[c] = powf((float)(m2 / rows) + eps, -0.5f);
+    }
+  }
+  if (tid <= ngroups) tickets[tid] = 0;
 }
 
 __global__ void k_bn_eval_stats(const float *running_mean, const float *running_var, int C, float eps,
@@ -131,17 +224,23 @@ __global__ __launch_bounds__(256) void k_add(const float *__restrict__ a, const 
   }
 }
 
-static int run_partial(const float *in, int rows, int C, void *scratch, size_t scratch_bytes,
-                       hipStream_t s, int *nblk_out) {
-  D3D_REQUIRE(C > 0 && C <= 4096, "batch norm: planes=%d out of range", C);
-  D3D_REQUIRE(C >= 256 ? (C % 256 == 0) : (256 % C == 0), "batch norm: planes=%d must divide 256 or be a multiple of 256", C);
+static int run_stats(const float *in, int rows, int C, void *scratch, size_t scratch_bytes, hipStream_t s, int mode,
+                     float *o0, float *o1, float *running_mean, float *running_var, float eps, float momentum) {
+  D3D_REQUIRE(C > 0 && C <= 4096 && C % 4 == 0, "batch norm: planes=%d must be a multiple of 4, <= 4096", C);
+  const int C4 = C / 4;
+  D3D_REQUIRE(kStatThreads % C4 == 0, "batch norm: planes/4=%d must divide %d", C4, kStatThreads);
   D3D_REQUIRE(scratch && scratch_bytes >= d3d_bn_scratch_bytes(C), "batch norm: scratch too small");
-  int nblk = kStatBlocks;
-  if (rows < nblk * 64) nblk = (rows + 63) / 64;
+  D3D_REQUIRE(((uintptr_t)in & 15) == 0, "batch norm: features must be 16-byte aligned");
+  const int RL = kStatThreads / C4;
+  int nblk = (rows + 8 * RL - 1) / (8 * RL);  // >= 8 passes of the row lanes per workgroup
+  if (nblk > kStatBlocks) nblk = kStatBlocks;
   if (nblk < 1) nblk = 1;
-  hipLaunchKernelGGL(k_bn_partial, dim3(nblk), dim3(256), 256 * 2 * sizeof(double), s, in, rows, C, (double *)scratch);
+  double *partial = (double *)((char *)scratch + kTicketBytes);
+  double *gpartial = partial + (size_t)kStatBlocks * 2 * C;
+  double *total = gpartial + (size_t)kStatMaxGroups * 2 * C;
+  hipLaunchKernelGGL(k_bn_stats, dim3(nblk), dim3(kStatThreads), 0, s, in, rows, C, (unsigned int *)scratch, partial,
+                     gpartial, total, mode, o0, o1, running_mean, running_var, eps, momentum);
   D3D_LAUNCH_CHECK();
-  *nblk_out = nblk;
   return D3D_OK;
 }
 
@@ -151,30 +250,22 @@ using namespace d3d;
 
 extern "C" {
 
-size_t d3d_bn_scratch_bytes(int planes) { return (size_t)kStatBlocks * 2 * planes * sizeof(double); }
+size_t d3d_bn_scratch_bytes(int planes) {
+  return kTicketBytes + (size_t)(kStatBlocks + kStatMaxGroups + 1) * 2 * planes * sizeof(double);
+}
 
 int d3d_bn_batch_stats(const float *in, int rows, int planes, float *mean, float *var_unbiased,
                        void *scratch, size_t scratch_bytes, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   D3D_REQUIRE(in && mean && var_unbiased && rows > 0, "bn_batch_stats: bad arguments");
-  int nblk;
-  int rc = run_partial(in, rows, planes, scratch, scratch_bytes, s, &nblk);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_bn_finish, dim3((planes + 31) / 32), dim3(256), 0, s, (const double *)scratch, nblk, rows, planes, 0, mean, var_unbiased, nullptr, nullptr, 0.f, 0.f);
-  D3D_LAUNCH_CHECK();
-  return D3D_OK;
+  return run_stats(in, rows, planes, scratch, scratch_bytes, s, 0, mean, var_unbiased, nullptr, nullptr, 0.f, 0.f);
 }
 
 int d3d_bn_batch_invstd(const float *in, int rows, int planes, float eps, float *mean, float *invstd,
                         void *scratch, size_t scratch_bytes, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   D3D_REQUIRE(in && mean && invstd && rows > 0, "bn_batch_invstd: bad arguments");
-  int nblk;
-  int rc = run_partial(in, rows, planes, scratch, scratch_bytes, s, &nblk);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_bn_finish, dim3((planes + 31) / 32), dim3(256), 0, s, (const double *)scratch, nblk, rows, planes, 2, mean, invstd, nullptr, nullptr, eps, 0.f);
-  D3D_LAUNCH_CHECK();
-  return D3D_OK;
+  return run_stats(in, rows, planes, scratch, scratch_bytes, s, 2, mean, invstd, nullptr, nullptr, eps, 0.f);
 }
 
 int d3d_bn_forward(const float *in, float *out, int rows, int planes, float *save_mean,
@@ -186,10 +277,8 @@ int d3d_bn_forward(const float *in, float *out, int rows, int planes, float *sav
   if (rows == 0) return D3D_OK;
   D3D_REQUIRE(in && out, "bn_forward: null features");
   if (train) {
-    int nblk;
-    int rc = run_partial(in, rows, planes, scratch, scratch_bytes, s, &nblk);
+    int rc = run_stats(in, rows, planes, scratch, scratch_bytes, s, 1, save_mean, save_invstd, running_mean, running_var, eps, momentum);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_bn_finish, dim3((planes + 31) / 32), dim3(256), 0, s, (const double *)scratch, nblk, rows, planes, 1, save_mean, save_invstd, running_mean, running_var, eps, momentum);
   } else {
     hipLaunchKernelGGL(k_bn_eval_stats, dim3((planes + 63) / 64), dim3(64), 0, s, running_mean, running_var, planes, eps, save_mean, save_invstd);
   }

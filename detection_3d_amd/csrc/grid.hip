@@ -332,33 +332,54 @@ __global__ __launch_bounds__(256) void k_count_rules(const int32_t *__restrict__
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(n_rules, (unsigned long long)(wsum[0] + wsum[1] + wsum[2] + wsum[3]));
 }
-__global__ void k_plan_transpose(const int32_t *__restrict__ nbr, const int32_t *__restrict__ rows,
-                                 int npos, int K, int32_t *__restrict__ nbrT) {
-  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long)npos * K) return;
-  int k = (int)(t / npos), p = (int)(t % npos);
-  int r = rows[p];
-  nbrT[t] = r >= 0 ? nbr[(size_t)r * K + k] : -1;
-}
-// one wave per block of 32 positions: wave64 ballot, low half tests offset k, high half k+1
-__global__ void k_blk_mask(const int32_t *__restrict__ nbrT, int npos, int K, int n_blk,
-                           uint32_t *__restrict__ blkmask) {
-  int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  int lane = threadIdx.x & 63;
-  if (wave >= n_blk) return;
-  uint32_t m = 0;
-  for (int k = 0; k < K; k += 2) {
-    int kk = k + (lane >> 5);
-    bool hit = kk < K && nbrT[(size_t)kk * npos + wave * 32 + (lane & 31)] >= 0;
-    unsigned long long bal = __ballot(hit);
-    if (bal & 0xffffffffull) m |= 1u << k;
-    if (bal >> 32) m |= 1u << (k + 1);
+// nbr[row][K] (row-major, site order) -> nbrT[K][npos] in plan order, through an LDS tile: a workgroup
+// owns kTP consecutive plan positions, reads their K-entry rows as contiguous 4K-byte runs and writes
+// kTP-entry runs of every offset's column.  The same pass pads rows[] to npos with -1 and derives the
+// per-block offset masks (ballot over the 32 positions of a block), so that the plan needs one launch
+// after the sort.  HBM-bound: 2 * npos * K * 4 bytes.
+static constexpr int kTP = 128;
+__global__ __launch_bounds__(256) void k_plan_finish(const int32_t *__restrict__ nbr, int32_t *__restrict__ rows,
+                                                     int n_rows, int npos, int K, int32_t *__restrict__ nbrT,
+                                                     uint32_t *__restrict__ blkmask) {
+  extern __shared__ int32_t tile[];  // [kTP][S], S odd
+  __shared__ int32_t rloc[kTP];
+  __shared__ uint32_t bm[kTP / 32];
+  const int S = K | 1;
+  const int p0 = blockIdx.x * kTP;
+  const int np = min(kTP, npos - p0);  // multiple of 32
+  if (threadIdx.x < kTP) {
+    const int p = p0 + threadIdx.x;
+    int r = -1;
+    if (p < n_rows)
+      r = rows[p];
+    else if (p < npos)
+      rows[p] = -1;
+    rloc[threadIdx.x] = r;
   }
-  if (lane == 0) blkmask[wave] = m;
-}
-__global__ void k_pad_rows(int32_t *rows, int n, int npos) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x + n;
-  if (i < npos) rows[i] = -1;
+  if (threadIdx.x < kTP / 32) bm[threadIdx.x] = 0;
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < np * K; idx += 256) {
+    const int p = idx / K, k = idx - p * K;
+    const int r = rloc[p];
+    tile[p * S + k] = r >= 0 ? nbr[(size_t)r * K + k] : -1;
+  }
+  __syncthreads();
+  // np is a multiple of 32 and 256 a multiple of 64: a wave covers two whole blocks of one offset
+  for (int idx = threadIdx.x; idx < kTP * K; idx += 256) {
+    const int k = idx / kTP, p = idx - k * kTP;
+    int v = -1;
+    if (p < np) {
+      v = tile[p * S + k];
+      nbrT[(size_t)k * npos + p0 + p] = v;
+    }
+    const unsigned long long bal = __ballot(v >= 0);
+    if ((threadIdx.x & 63) == 0) {
+      if (bal & 0xffffffffull) atomicOr(&bm[p >> 5], 1u << k);
+      if (bal >> 32) atomicOr(&bm[(p >> 5) + 1], 1u << k);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < np / 32) blkmask[p0 / 32 + threadIdx.x] = bm[threadIdx.x];
 }
 
 // `mask_in` (may be null): per-row offset masks already computed by the caller together with the
@@ -395,10 +416,8 @@ int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan
   hipLaunchKernelGGL(k_sort_key, grid1d(n_rows), dim3(256), 0, s, mask, key, iota, n_rows, K);
   int rc = sort_pairs_u32(key, key_sorted, iota, rows, n_rows, K <= 27 ? K + 5 : K, A, s, true);
   if (rc) return rc;
-  if (npos > n_rows) hipLaunchKernelGGL(k_pad_rows, grid1d(npos - n_rows), dim3(256), 0, s, rows, n_rows, npos);
-  hipLaunchKernelGGL(k_plan_transpose, grid1d((long)npos * K), dim3(256), 0, s, nbr, rows, npos, K, nbrT);
-  hipLaunchKernelGGL(k_blk_mask, grid1d((long)plan.n_blk * 64), dim3(256), 0, s, nbrT, npos, K,
-                     plan.n_blk, blkmask);
+  hipLaunchKernelGGL(k_plan_finish, dim3((npos + kTP - 1) / kTP), dim3(256), (size_t)kTP * (K | 1) * sizeof(int32_t),
+                     s, nbr, rows, n_rows, npos, K, nbrT, blkmask);
   D3D_LAUNCH_CHECK();
   A.used = mark;  // scratch released (stream-ordered reuse)
   return D3D_OK;

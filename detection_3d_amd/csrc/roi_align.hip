@@ -105,68 +105,147 @@ __global__ __launch_bounds__(256) void k_roi_dense(const float *__restrict__ inp
   out[index] = acc / count;
 }
 
-// Sparse variant.  Block = one RoI x one chunk of 64 channels; a wave walks bins; inside a bin the
-// 64 lanes first resolve (sub-sample, corner) -> (row, weight) in parallel through the hash grid
-// (8 sub-samples x 8 corners per step), then every lane accumulates its channel over the
-// broadcast list, reading feature rows coalesced.  The [64 x bins] tile is transposed through LDS
-// so that the [K, C, ph, pw, pz] output is written in contiguous runs.
-static constexpr int kRoiCch = 64;
+// Sparse variant.  Block = one RoI x one chunk of 128 channels (lane = 2 adjacent channels); a wave owns
+// groups of kRoiG consecutive bins.  Per group and per step of 8 sub-samples the 64 lanes first resolve
+// (sub-sample, corner) -> (row, weight) through the hash grid for all kRoiG bins at once (kRoiG independent
+// probes in flight per lane), compact the taps that exist into a per-bin LDS list, and then every lane
+// accumulates its two channels over the lists with 8 independent feature-row loads in flight (each a
+// coalesced 512-B read of the wave).  Everything is latency-bound L2 traffic: the feature map of a pyramid
+// level is a few MB; what matters is the number of loads in flight, not bytes.
+// layout 0: out[n][c][ph][pw][pz] (the reference's); layout 1: out[n][ph][pw][c][pz] (rows of the box head's
+// [1,1,pz] convolution seen as a GEMM).  roi_levels (optional): only RoIs with roi_levels[i] == level are pooled.
+static constexpr int kRoiG = 8;
+static constexpr int kRoiCch = 128;
+__device__ __forceinline__ void roi_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __global__ __launch_bounds__(256) void k_roi_sparse(
-    const HashEntry *__restrict__ tab, int cap, const float *__restrict__ feats, int C, int H, int W, int Z, const float *__restrict__ rois,
-    float spatial_scale, int PH, int PW, int PZ, int sampling_ratio, float *__restrict__ out) {
-  extern __shared__ float tile[];  // [kRoiCch][NB + 1]
+    const HashEntry *__restrict__ tab, int cap, const float *__restrict__ feats, int C, int H, int W, int Z,
+    const float *__restrict__ rois, const int32_t *__restrict__ roi_levels, int level, float spatial_scale, int PH,
+    int PW, int PZ, int sampling_ratio, int layout, float *__restrict__ out) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  __shared__ int2 list[4][kRoiG][64];  // (row, weight bits) of the taps that exist
   const int n = blockIdx.x, cc = blockIdx.y;
-  const int NB = PH * PW * PZ, LD = NB + 1;
+  if (roi_levels && roi_levels[n] != level) return;  // pooled from another pyramid level
+  const int NB = PH * PW * PZ;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const RoiGeom g = roi_geom(rois + (size_t)n * 8, spatial_scale, PH, PW, PZ, sampling_ratio);
   const int NS = g.gh * g.gw * g.gz;
   const float count = (float)NS;
-  const int c = cc * kRoiCch + lane;
-  const bool cok = c < C;
-  for (int bin = wave; bin < NB; bin += 4) {
-    const int pz = bin % PZ, pw = (bin / PZ) % PW, ph = bin / (PZ * PW);
-    float acc = 0.f;
+  const int c0 = cc * kRoiCch + 2 * lane;
+  const bool ok0 = c0 < C, ok1 = c0 + 1 < C;
+  const bool pair = ok1 && (C % 2 == 0);  // 8-byte aligned pair load
+  const size_t n_out = (size_t)n;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  auto load2 = [&](int row) -> f32x2 {
+    const float *p = feats + (size_t)row * C + c0;
+    f32x2 v = {0.f, 0.f};
+    if (pair)
+      v = *(const f32x2 *)p;
+    else {
+      if (ok0) v[0] = p[0];
+      if (ok1) v[1] = p[1];
+    }
+    return v;
+  };
+  const int ngroups = (NB + kRoiG - 1) / kRoiG;
+  for (int grp = wave; grp < ngroups; grp += 4) {
+    const int b0 = grp * kRoiG;
+    f32x2 acc[kRoiG];
+#pragma unroll
+    for (int gi = 0; gi < kRoiG; gi++) acc[gi] = {0.f, 0.f};
     for (int s0 = 0; s0 < NS; s0 += 8) {
-      // ---- lanes = (sub-sample s0 + lane/8, corner lane%8) ----
+      // ---- lanes = (sub-sample s0 + lane/8, corner lane%8), kRoiG bins at once ----
       const int s = s0 + (lane >> 3), corner = lane & 7;
-      int row = -1;
-      float wgt = 0.f;
-      if (s < NS) {
-        const int iz = s % g.gz, ix = (s / g.gz) % g.gw, iy = s / (g.gz * g.gw);
-        float y, x, z;
-        sample_pos(g, ph, pw, pz, iy, ix, iz, y, x, z);
-        Tri t;
-        if (tri_setup(y, x, z, H, W, Z, t)) {
-          const int zb = corner >> 2, yb = (corner >> 1) & 1, xb = corner & 1;
-          wgt = (yb ? t.ly : t.hy) * (xb ? t.lx : t.hx) * (zb ? t.lz : t.hz);
-          // dense index [y][x][z]: y runs over the tensor's 1st spatial axis, x over the 2nd
-          row = hash_find(tab, cap, pack_key(g.b, yb ? t.yh : t.yl, xb ? t.xh : t.xl, zb ? t.zh : t.zl));
+      const int iz = s % g.gz, ix = (s / g.gz) % g.gw, iy = s / (g.gz * g.gw);
+      const int zb = corner >> 2, yb = (corner >> 1) & 1, xb = corner & 1;
+      int row[kRoiG];
+      float wgt[kRoiG];
+#pragma unroll
+      for (int gi = 0; gi < kRoiG; gi++) {
+        const int bin = b0 + gi;
+        row[gi] = -1;
+        wgt[gi] = 0.f;
+        if (s < NS && bin < NB) {
+          const int pz = bin % PZ, pw = (bin / PZ) % PW, ph = bin / (PZ * PW);
+          float y, x, z;
+          sample_pos(g, ph, pw, pz, iy, ix, iz, y, x, z);
+          Tri t;
+          if (tri_setup(y, x, z, H, W, Z, t)) {
+            wgt[gi] = (yb ? t.ly : t.hy) * (xb ? t.lx : t.hx) * (zb ? t.lz : t.hz);
+            // dense index [y][x][z]: y runs over the tensor's 1st spatial axis, x over the 2nd
+            row[gi] = hash_find(tab, cap, pack_key(g.b, yb ? t.yh : t.yl, xb ? t.xh : t.xl, zb ? t.zh : t.zl));
+          }
         }
       }
-      // ---- lanes = channels ----
-      const unsigned long long present = __ballot(row >= 0);
-#pragma unroll 1
-      for (int ss = 0; ss < 8; ss++) {
-        unsigned long long m = (present >> (ss * 8)) & 0xffull;
-        if (!m) continue;
-        float val = 0.f;
-        while (m) {
-          const int cr = __builtin_ctzll(m);
-          m &= m - 1;
-          const int src = ss * 8 + cr;
-          const int rr = __shfl(row, src, 64);
-          const float ww = __shfl(wgt, src, 64);
-          if (cok) val += ww * feats[(size_t)rr * C + c];
+      int cnt[kRoiG];
+#pragma unroll
+      for (int gi = 0; gi < kRoiG; gi++) {
+        const unsigned long long m = __ballot(row[gi] >= 0);
+        cnt[gi] = __popcll(m);
+        if (row[gi] >= 0) list[wave][gi][__popcll(m & lt)] = make_int2(row[gi], __float_as_int(wgt[gi]));
+      }
+      roi_wave_sync();
+      // ---- lanes = channel pairs: taps in (sub-sample, corner) order, batches of independent row loads ----
+#pragma unroll
+      for (int gi = 0; gi < kRoiG; gi++) {
+        const int2 *L = list[wave][gi];
+        const int nc = cnt[gi];
+        int i = 0;
+        for (; i + 8 <= nc; i += 8) {
+          int2 e[8];
+          f32x2 v[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) e[j] = L[i + j];
+#pragma unroll
+          for (int j = 0; j < 8; j++) v[j] = load2(e[j].x);
+#pragma unroll
+          for (int j = 0; j < 8; j++) acc[gi] += __int_as_float(e[j].y) * v[j];
         }
-        acc += val;
+        if (i + 4 <= nc) {
+          int2 e[4];
+          f32x2 v[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) e[j] = L[i + j];
+#pragma unroll
+          for (int j = 0; j < 4; j++) v[j] = load2(e[j].x);
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[gi] += __int_as_float(e[j].y) * v[j];
+          i += 4;
+        }
+        if (i + 2 <= nc) {
+          const int2 e0 = L[i], e1 = L[i + 1];
+          const f32x2 v0 = load2(e0.x), v1 = load2(e1.x);
+          acc[gi] += __int_as_float(e0.y) * v0;
+          acc[gi] += __int_as_float(e1.y) * v1;
+          i += 2;
+        }
+        if (i < nc) {
+          const int2 e0 = L[i];
+          acc[gi] += __int_as_float(e0.y) * load2(e0.x);
+        }
+      }
+      roi_wave_sync();  // the lists are rewritten by the next step
+    }
+#pragma unroll
+    for (int gi = 0; gi < kRoiG; gi++) {
+      const int bin = b0 + gi;
+      if (bin >= NB) break;
+      const f32x2 r = acc[gi] / count;
+      if (layout == 0) {
+        float *o = out + (n_out * C + c0) * NB + bin;
+        if (ok0) o[0] = r[0];
+        if (ok1) o[NB] = r[1];
+      } else {
+        const int pz = bin % PZ, cell = bin / PZ;
+        float *o = out + ((n_out * (size_t)(PH * PW) + cell) * C + c0) * PZ + pz;
+        if (ok0) o[0] = r[0];
+        if (ok1) o[PZ] = r[1];
       }
     }
-    tile[lane * LD + bin] = acc / count;
   }
-  __syncthreads();
-  const int nch = min(kRoiCch, C - cc * kRoiCch);
-  float *o = out + ((size_t)n * C + (size_t)cc * kRoiCch) * NB;
-  for (int idx = threadIdx.x; idx < nch * NB; idx += 256) o[idx] = tile[(idx / NB) * LD + idx % NB];
 }
 
 // Dense backward, _C.roi_align_rotated_3d_backward (ROIAlignRotated3D_cuda.cu:238-354): one thread per
@@ -206,22 +285,23 @@ __global__ __launch_bounds__(256) void k_roi_dense_bwd(const float *__restrict__
 // Backward of the sparse variant: the dense gradient of RoIAlignRotated3DBackwardFeature (:238-354)
 // restricted to the active sites (what SparseToDense_updateGradInput would gather back).  Keeps the
 // backward's own bound test `z > zsize` (:190).  fp32 atomics, like the reference.
+static constexpr int kRoiBwdCch = 64;
 __global__ __launch_bounds__(256) void k_roi_sparse_bwd(
     const HashEntry *__restrict__ tab, int cap, int C, int H, int W, int Z, const float *__restrict__ rois,
     float spatial_scale, int PH, int PW, int PZ, int sampling_ratio, const float *__restrict__ top_diff,
     float *__restrict__ d_feats) {
-  extern __shared__ float tile[];  // [kRoiCch][NB + 1]
+  extern __shared__ float tile[];  // [kRoiBwdCch][NB + 1]
   const int n = blockIdx.x, cc = blockIdx.y;
   const int NB = PH * PW * PZ, LD = NB + 1;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int nch = min(kRoiCch, C - cc * kRoiCch);
-  const float *g0 = top_diff + ((size_t)n * C + (size_t)cc * kRoiCch) * NB;
+  const int nch = min(kRoiBwdCch, C - cc * kRoiBwdCch);
+  const float *g0 = top_diff + ((size_t)n * C + (size_t)cc * kRoiBwdCch) * NB;
   for (int idx = threadIdx.x; idx < nch * NB; idx += 256) tile[(idx / NB) * LD + idx % NB] = g0[idx];
   __syncthreads();
   const RoiGeom g = roi_geom(rois + (size_t)n * 8, spatial_scale, PH, PW, PZ, sampling_ratio);
   const int NS = g.gh * g.gw * g.gz;
   const float count = (float)NS;
-  const int c = cc * kRoiCch + lane;
+  const int c = cc * kRoiBwdCch + lane;
   const bool cok = c < C;
   for (int bin = wave; bin < NB; bin += 4) {
     const int pz = bin % PZ, pw = (bin / PZ) % PW, ph = bin / (PZ * PW);
@@ -275,7 +355,8 @@ int d3d_roi_align_rotated_3d_forward(const float *input, int B, int C, int H, in
 int d3d_roi_align_rotated_3d_sparse_forward(d3d_meta *m, const int *size, const float *feats, int C,
                                             const int *crop, const float *rois, int K,
                                             float spatial_scale, int ph, int pw, int pz,
-                                            int sampling_ratio, float *out, void *stream) {
+                                            int sampling_ratio, const int *roi_levels, int level, int layout,
+                                            float *out, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   D3D_REQUIRE(m && size && crop && C > 0 && K >= 0 && ph > 0 && pw > 0 && pz > 0, "roi_align_sparse: bad arguments");
   auto it = m->grids.find(Size3{size[0], size[1], size[2]});
@@ -285,11 +366,10 @@ int d3d_roi_align_rotated_3d_sparse_forward(d3d_meta *m, const int *size, const 
   }
   if (K == 0) return D3D_OK;
   D3D_REQUIRE(feats && rois && out, "roi_align_sparse: null pointer");
+  D3D_REQUIRE(layout == 0 || layout == 1, "roi_align_sparse: layout must be 0 ([K,C,ph,pw,pz]) or 1 ([K,ph,pw,C,pz])");
   const Grid &g = it->second;
-  const int NB = ph * pw * pz;
-  size_t lds = (size_t)kRoiCch * (NB + 1) * sizeof(float);
-  D3D_REQUIRE(lds <= 64 * 1024, "roi_align_sparse: pooled volume %d too large", NB);
-  hipLaunchKernelGGL(k_roi_sparse, dim3(K, (C + kRoiCch - 1) / kRoiCch), dim3(256), lds, s, g.tab, g.cap, feats, C, crop[0], crop[1], crop[2], rois, spatial_scale, ph, pw, pz, sampling_ratio, out);
+  hipLaunchKernelGGL(k_roi_sparse, dim3(K, (C + kRoiCch - 1) / kRoiCch), dim3(256), 0, s, g.tab, g.cap, feats, C,
+                     crop[0], crop[1], crop[2], rois, roi_levels, level, spatial_scale, ph, pw, pz, sampling_ratio, layout, out);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }
@@ -326,9 +406,9 @@ int d3d_roi_align_rotated_3d_sparse_backward(d3d_meta *m, const int *size, const
   D3D_REQUIRE(top_diff && rois && d_feats, "roi_align_sparse_backward: null pointer");
   const Grid &g = it->second;
   const int NB = ph * pw * pz;
-  size_t lds = (size_t)kRoiCch * (NB + 1) * sizeof(float);
+  size_t lds = (size_t)kRoiBwdCch * (NB + 1) * sizeof(float);
   D3D_REQUIRE(lds <= 64 * 1024, "roi_align_sparse_backward: pooled volume %d too large", NB);
-  hipLaunchKernelGGL(k_roi_sparse_bwd, dim3(K, (C + kRoiCch - 1) / kRoiCch), dim3(256), lds, s, g.tab, g.cap, C,
+  hipLaunchKernelGGL(k_roi_sparse_bwd, dim3(K, (C + kRoiBwdCch - 1) / kRoiBwdCch), dim3(256), lds, s, g.tab, g.cap, C,
                      crop[0], crop[1], crop[2], rois, spatial_scale, ph, pw, pz, sampling_ratio, top_diff, d_feats);
   D3D_LAUNCH_CHECK();
   return D3D_OK;

@@ -23,7 +23,8 @@ from . import box_ops
 from . import sparseconvnet as scn
 from . import training as T
 from .config import class_to_label
-from .roi_align_rotated_3d import roi_align_rotated_3d_sparse
+from .roi_align_rotated_3d import roi_align_rotated_3d_sparse, roi_align_rotated_3d_sparse_into
+from .sparseconvnet import SCN
 
 
 class SeperateClassifier(object):
@@ -245,10 +246,23 @@ class Pooler(nn.Module):
         dif = torch.abs(torch.tensor(self.scales, device=boxes.device)[None, :] - rate[:, None])
         return torch.argmin(dif, 1)
 
-    def forward(self, x, boxes_pixels):
+    def forward(self, x, boxes_pixels, channels_inner=False):
+        """-> [K, C, ph, pw, pz]; channels_inner (inference only): [K, ph, pw, C, pz]."""
         with torch.no_grad():
             rois = convert_to_roi_format(boxes_pixels)
         ph, pw, pz = self.output_size
+        if not torch.is_grad_enabled():
+            # one result tensor filled in place by one launch per level (no nonzero / index_put, one host sync)
+            K, C = rois.shape[0], x[0].features.shape[1]
+            out = torch.empty((K, ph, pw, C, pz) if channels_inner else (K, C, ph, pw, pz), dtype=torch.float32,
+                              device=rois.device)
+            levels = self.map_levels(boxes_pixels).to(torch.int32) if len(self.scales) > 1 else None
+            crops = (torch.stack([f.get_spatial_locations()[:, :3].max(0)[0] for f in x]) + 1).tolist()
+            for level, (fmap, scale) in enumerate(zip(x, self.scales)):
+                roi_align_rotated_3d_sparse_into(out, fmap, rois, scale, self.sampling_ratio, crop=crops[level],
+                                                 roi_levels=levels, level=level, channels_inner=channels_inner)
+            return out
+        assert not channels_inner
         if len(self.scales) == 1:
             return roi_align_rotated_3d_sparse(x[0], rois, self.scales[0], ph, pw, pz, self.sampling_ratio)
         levels = self.map_levels(boxes_pixels)
@@ -293,9 +307,40 @@ class FPN2MLPFeatureExtractor(nn.Module):
             return relu(bn(y.contiguous()))
         return self.conv3d(pooled)
 
+    def _fc6_rows_weight(self, cells):
+        """fc6.weight with its input index reordered from (channel, cell) to (cell, channel): the operand for the
+        row-major [K, cells, rep] activations of the inference path (cached per weight version)."""
+        w = self.fc6.weight
+        key = (w.data_ptr(), w._version, cells)
+        if getattr(self, "_fc6_rows", (None,))[0] != key:
+            rep = w.shape[1] // cells
+            self._fc6_rows = (key, w.detach().view(w.shape[0], rep, cells).permute(0, 2, 1).reshape(w.shape[0], -1)
+                              .contiguous())
+        return self._fc6_rows[1]
+
+    def _forward_rows(self, x0, p):
+        """Inference path without layout changes: the pooler writes [K, ph, pw, C, pz], whose rows feed the
+        [1,1,pz] convolution as a GEMM; BatchNorm3d + ReLU is one row-wise BatchNorm over [K*ph*pw, rep]
+        (batch statistics, biased variance: F.batch_norm in training mode), fc6 reads the rows in place."""
+        conv, bn = self.conv3d[0], self.conv3d[1]
+        pooled = self.pooler(x0, p, channels_inner=True)
+        K, ph, pw, C, pz = pooled.shape
+        y = torch.addmm(conv.bias, pooled.view(K * ph * pw, C * pz), conv.weight.view(conv.out_channels, C * pz).t())
+        rep = y.shape[1]
+        out, sm, si = y.new_empty(0), y.new_empty(rep), y.new_empty(rep)
+        SCN.BatchNormalization_updateOutput(y, out, sm, si, y.new_zeros(rep), y.new_ones(rep), bn.weight, bn.bias,
+                                            bn.eps, 0.0, True, 0.0)
+        h = torch.addmm(self.fc6.bias, out.view(K, ph * pw * rep), self._fc6_rows_weight(ph * pw).t())
+        return F.relu(self.fc7(F.relu(h)))
+
     def forward(self, x0, proposals):
         p = proposals.clone()
         p[:, 0:6] *= self.voxel_scale                                           # convert_metric_to_pixel
+        conv, bn = self.conv3d[0], self.conv3d[1]
+        if (not torch.is_grad_enabled() and tuple(conv.kernel_size) == (1, 1, self.pooler.output_size[2])
+                and tuple(conv.stride) == (1, 1, 1) and (bn.training or not bn.track_running_stats)
+                and proposals.shape[0] > 0):
+            return self._forward_rows(x0, p)
         x1 = self._head_conv(self.pooler(x0, p))
         x2 = x1.reshape(x1.size(0), -1)
         return F.relu(self.fc7(F.relu(self.fc6(x2))))

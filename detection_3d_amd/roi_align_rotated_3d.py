@@ -61,7 +61,7 @@ class _RoiSparseFn(torch.autograd.Function):
         out = torch.empty((K, C, ph, pw, pz), dtype=torch.float32, device=f.device)
         check(lib().d3d_roi_align_rotated_3d_sparse_forward(
             metadata._h, ints(spatial_size), ptr(f), C, ints(crop), ptr(rois), K, float(spatial_scale), ph, pw, pz,
-            int(sampling_ratio), ptr(out), stream_of()))
+            int(sampling_ratio), None, 0, 0, ptr(out), stream_of()))
         ctx.save_for_backward(rois)
         ctx.args = (metadata, spatial_size, crop, spatial_scale, ph, pw, pz, sampling_ratio, f.shape)
         return out
@@ -90,6 +90,32 @@ def roi_align_rotated_3d_sparse(feat_s3d, rois, spatial_scale, pooled_height, po
     return _RoiSparseFn.apply(feat_s3d.features, r, feat_s3d.metadata, feat_s3d.spatial_size.tolist(),
                               [int(c) for c in crop], spatial_scale, pooled_height, pooled_width, pooled_zsize,
                               sampling_ratio)
+
+
+def roi_align_rotated_3d_sparse_into(out, feat_s3d, rois, spatial_scale, sampling_ratio, crop=None,
+                                     roi_levels=None, level=0, channels_inner=True):
+    """Inference-only form of the above for the multi-level pooler (poolers_3d.py:150-168): pools into `out`
+    ([K, ph, pw, C, pz] if channels_inner else [K, C, ph, pw, pz]) the RoIs whose roi_levels[i] == level
+    (all of them when roi_levels is None) and leaves the other slots untouched."""
+    f = feat_s3d.features.contiguous()
+    r = rois.detach().to(torch.float32).contiguous()
+    require_gpu(f, r, out)
+    assert out.is_contiguous() and out.dtype == torch.float32 and out.shape[0] == r.shape[0]
+    if channels_inner:
+        _, ph, pw, C, pz = out.shape
+    else:
+        _, C, ph, pw, pz = out.shape
+    assert C == f.shape[1]
+    if crop is None:
+        loc = feat_s3d.get_spatial_locations()
+        crop = (loc[:, :3].max(0)[0] + 1).tolist()
+    if roi_levels is not None:
+        assert roi_levels.dtype == torch.int32 and roi_levels.is_contiguous() and roi_levels.shape[0] == r.shape[0]
+    check(lib().d3d_roi_align_rotated_3d_sparse_forward(
+        feat_s3d.metadata._h, ints(feat_s3d.spatial_size.tolist()), ptr(f), C, ints([int(c) for c in crop]), ptr(r),
+        r.shape[0], float(spatial_scale), ph, pw, pz, int(sampling_ratio), ptr(roi_levels), int(level),
+        1 if channels_inner else 0, ptr(out), stream_of()))
+    return out
 
 
 class ROIAlignRotated3D(torch.nn.Module):

@@ -28,6 +28,20 @@ def _scratch(device, nbytes):
     return buf
 
 
+_BN_SCRATCH = {}
+
+
+def _bn_scratch(device, nbytes):
+    """Scratch of the BatchNorm statistics kernels: starts with a ticket word that must be zero on entry
+    (the kernel leaves it zero), so it is zero-initialised and never shared with other ops."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    buf = _BN_SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.zeros(max(nbytes, 1 << 22), dtype=torch.uint8, device=device)
+        _BN_SCRATCH[key] = buf
+    return buf
+
+
 class ConvProfiler(object):
     """Optional per-launch timing of the sparse convolutions with HIP events recorded on the
     stream the kernels are launched on (bench.py's roofline leg).  Off by default.
@@ -223,7 +237,7 @@ def batch_mean_invstd(features, eps):
     mean = torch.empty(planes, dtype=torch.float32, device=features.device)
     invstd = torch.empty_like(mean)
     nbytes = lib().d3d_bn_scratch_bytes(planes)
-    scratch = _scratch(features.device, nbytes)
+    scratch = _bn_scratch(features.device, nbytes)
     check(lib().d3d_bn_batch_invstd(ptr(features), rows, planes, float(eps), ptr(mean), ptr(invstd), ptr(scratch),
                                     scratch.numel(), stream_of()))
     return mean, invstd
@@ -327,7 +341,7 @@ def BatchNormalization_updateOutput(input_features, output_features, saveMean, s
     w = weight if (weight is not None and weight.numel()) else None
     b = bias if (bias is not None and bias.numel()) else None
     nbytes = lib().d3d_bn_scratch_bytes(planes)
-    scratch = _scratch(input_features.device, nbytes)
+    scratch = _bn_scratch(input_features.device, nbytes)
     check(lib().d3d_bn_forward(ptr(input_features), ptr(output_features), rows, planes, ptr(saveMean),
                                ptr(saveInvStd), ptr(runningMean), ptr(runningVar), ptr(w), ptr(b),
                                float(eps), float(momentum), int(bool(train)), float(leakiness),
@@ -341,7 +355,7 @@ def batch_stats(features):
     mean = torch.empty(planes, dtype=torch.float32, device=features.device)
     var = torch.empty_like(mean)
     nbytes = lib().d3d_bn_scratch_bytes(planes)
-    scratch = _scratch(features.device, nbytes)
+    scratch = _bn_scratch(features.device, nbytes)
     check(lib().d3d_bn_batch_stats(ptr(features), rows, planes, ptr(mean), ptr(var), ptr(scratch),
                                    scratch.numel(), stream_of()))
     return mean, var

@@ -188,6 +188,9 @@ int d3d_bn_batch_invstd(const float *in, int rows, int planes, float eps, float 
  * for a consumer of a deferred BatchNorm that is not a convolution.                                   */
 int d3d_bn_apply(const float *in, float *out, int rows, int planes, const float *mean, const float *invstd,
                  const float *weight, const float *bias, float leakiness, void *stream);
+/* scratch of d3d_bn_forward / d3d_bn_batch_stats / d3d_bn_batch_invstd: device memory of this many bytes whose
+ * first 256 bytes (ticket counters) are ZERO before the first call; the library leaves them zero.  planes must
+ * be a multiple of 4 with planes/4 dividing 1024 (planes = 4, 8, ..., 4096).                                     */
 size_t d3d_bn_scratch_bytes(int planes);
 /* sparseconvnet/utils.py:61-66 add_feature_planes / tables.py AddTable: out = a + b. */
 int d3d_add(const float *a, const float *b, float *out, size_t n, void *stream);
@@ -204,12 +207,17 @@ int d3d_roi_align_rotated_3d_forward(const float *input, int B, int C, int H, in
                                      int pz, int sampling_ratio, float *out, void *stream);
 /* Same result sampled straight from the sparse tensor through the hash grid (no 1 GB dense
  * map): equals sparse_3d_to_dense_2d (sparseconvnet/tools_3d_2d.py:7-48, crop to the occupied
- * extent crop_host[3]) followed by the dense op.                                             */
+ * extent crop_host[3]) followed by the dense op.
+ * roi_levels (device int32[K], nullable): only RoIs with roi_levels[i] == level are pooled, the other output
+ * slots are left untouched, so that the per-level calls of poolers_3d.py:150-168 fill one result tensor
+ * without nonzero / index / index_put passes.
+ * layout 0: out[slot][C][ph][pw][pz] (the reference's); layout 1: out[slot][ph][pw][C][pz], the row-major
+ * operand of the box head's [1,1,pz] convolution (roi_box_feature_extractors.py:68-77) as a GEMM.   */
 int d3d_roi_align_rotated_3d_sparse_forward(d3d_meta *m, const int *spatial_size_host,
                                             const float *feats, int C, const int *crop_host,
                                             const float *rois, int K, float spatial_scale, int ph,
-                                            int pw, int pz, int sampling_ratio, float *out,
-                                            void *stream);
+                                            int pw, int pz, int sampling_ratio, const int *roi_levels,
+                                            int level, int layout, float *out, void *stream);
 
 /* a17. rotate_iou_gpu_eval (second/core/non_max_suppression/nms_gpu.py:614-664) incl.
  * check_same_boxes: boxes [N,5], query [K,5] -> out [N,K].                                   */

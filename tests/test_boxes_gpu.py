@@ -161,6 +161,22 @@ def test_roi_align_dense_and_sparse(dev):
     assert _close(got_d, want, 1e-5)
     assert _close(got_s, want, 1e-5)
     assert np.abs(want).max() > 0.1
+    # inference forms: channels-inner layout and per-level selection write the same numbers elsewhere
+    from detection_3d_amd.roi_align_rotated_3d import roi_align_rotated_3d_sparse_into
+    gs = torch.from_numpy(got_s).to(dev)
+    inner = torch.full((K, 6, 8, C, 4), 7.0, device=dev)
+    roi_align_rotated_3d_sparse_into(inner, t, r, 1.0 / 8, 2, channels_inner=True)
+    assert torch.equal(inner.permute(0, 3, 1, 2, 4), gs)
+    levels = torch.from_numpy((np.arange(K) % 3 == 0).astype(np.int32)).to(dev)
+    part = torch.full((K, C, 6, 8, 4), 7.0, device=dev)
+    roi_align_rotated_3d_sparse_into(part, t, r, 1.0 / 8, 2, roi_levels=levels, level=1, channels_inner=False)
+    sel = levels.bool()
+    assert torch.equal(part[sel], gs[sel]) and bool((part[~sel] == 7.0).all())
+    # odd channel count and adaptive sampling (sampling_ratio 0)
+    t37 = scn.SparseConvNetTensor(t.features[:, :37].contiguous(), t.metadata, t.spatial_size)
+    want37 = oracle.roi_align_rotated_3d(dense[:, :37].copy(), rois[:12], 1.0 / 8, 3, 2, 5, 0)
+    got37 = roi_align_rotated_3d_sparse(t37, r[:12].contiguous(), 1.0 / 8, 3, 2, 5, 0).cpu().numpy()
+    assert _close(got37, want37, 1e-5)
 
 
 @pytest.mark.parametrize("cap", [1, 17, 64, 300])

@@ -150,8 +150,8 @@ def test_conv_ops(dev, cin, cout):
 def test_batchnorm(dev):
     from detection_3d_amd import sparseconvnet as scn
     rng = np.random.RandomState(5)
-    for C in (32, 64, 128, 256):
-        x = (rng.randn(5000, C) * 2 + 0.5).astype(np.float32)
+    for C, rows in ((32, 5000), (64, 5000), (128, 4999), (256, 5000), (8, 37), (512, 3001), (1024, 700)):
+        x = (rng.randn(rows, C) * 2 + 0.5).astype(np.float32)
         t = scn.SparseConvNetTensor(torch.from_numpy(x).to(dev), None, torch.tensor([8, 8, 8]))
         # eval, batch statistics (TRACK_RUNNING_STATS False)
         bn = scn.BatchNormLeakyReLU(C, momentum=0.95, leakiness=0, track_running_stats=False).to(dev).eval()
