@@ -84,6 +84,53 @@ def _nms_sorted(boxes_sorted, thresh, max_keep=0):
     return keep, nk
 
 
+def nms_3d_batched(boxes, order, counts, n_max, iou_threshold, aug_thickness=(0.0, 0.0), max_keep=0):
+    """d3d_rotate_nms_3d_batched: `boxes` [M,7]; segment b's candidates are boxes[order[b, i]], i < counts[b]
+    (order [B, stride] int32 in descending score order; None: one segment = boxes[:n_max] as they are;
+    counts [B] int32 on the device or None) -> keep int32 [B, n_max] (box indices, selection order), n_keep [B]."""
+    boxes = _f32c(boxes)
+    require_gpu(boxes)
+    dev = boxes.device
+    if order is None:
+        B, stride = 1, 0
+    else:
+        assert order.dtype == torch.int32 and order.is_contiguous() and order.dim() == 2
+        B, stride = order.shape
+    if counts is not None:
+        assert counts.dtype == torch.int32 and counts.is_contiguous() and counts.shape[0] == B
+    nbytes = lib().d3d_nms_batched_scratch_bytes(B, n_max)
+    buf = _NMS_SCRATCH.get(dev.index)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        _NMS_SCRATCH[dev.index] = buf
+    keep = torch.empty((B, max(n_max, 1)), dtype=torch.int32, device=dev)
+    nk = torch.zeros(B, dtype=torch.int32, device=dev)
+    check(lib().d3d_rotate_nms_3d_batched(ptr(boxes), ptr(order), stride, ptr(counts), B, n_max, float(iou_threshold),
+                                          float(aug_thickness[0]), float(aug_thickness[1]), int(max_keep or 0),
+                                          ptr(keep), ptr(nk), ptr(buf), buf.numel(), stream_of()))
+    return keep, nk
+
+
+def nms_3d_presorted(bbox3d, nms_thresh, nms_aug_thickness=None, max_proposals=-1, flag=''):
+    """nms_3d_clamped for boxes already in descending score order (the RPN's top-k): no re-sort, the size clamp
+    happens inside the kernel.  -> kept positions (int64), in score order."""
+    if nms_aug_thickness is None:
+        nms_aug_thickness = [0, 0]
+    if flag == 'rpn_post':
+        assert max_proposals > 100, max_proposals
+    elif flag == 'roi_post':
+        assert max_proposals == -1
+    else:
+        raise NotImplementedError(flag)
+    if max_proposals < 0:
+        max_proposals = 500
+    n = min(bbox3d.shape[0], 2000)                                       # pre_max_size
+    if n == 0:
+        return torch.zeros([0], dtype=torch.int64, device=bbox3d.device)
+    keep, nk = nms_3d_batched(bbox3d, None, None, n, nms_thresh, nms_aug_thickness, max_proposals)
+    return keep[0, :int(nk.item())].long()
+
+
 def rotate_nms_3d(rbboxes, scores, pre_max_size=None, post_max_size=None, iou_threshold=0.5, flag=''):
     """rbboxes [n,7] yx_zb, scores [n] -> LongTensor of kept indices into the input, in score order."""
     rbboxes, scores = _f32c(rbboxes), _f32c(scores)

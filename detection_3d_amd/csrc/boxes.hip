@@ -305,18 +305,33 @@ __device__ __forceinline__ bool quads_separated(const float *a, const float *b, 
   }
   return false;
 }
-__global__ void k_nms_prep(const float *__restrict__ boxes, int n, NmsBox *__restrict__ rec) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float *b = boxes + (size_t)i * 7;
+// A batch of independent candidate lists ("segments", e.g. the classes of the box head): candidate i of
+// segment b is box order[b*stride + i] (b*stride + i without `order`), i < counts[b] (n_max without `counts`),
+// already in descending score order.
+struct NmsSegs {
+  const int32_t *order;
+  const int32_t *counts;
+  int stride, n_max;
+};
+__device__ __forceinline__ int seg_count(const NmsSegs &g, int b) { return g.counts ? min(g.counts[b], g.n_max) : g.n_max; }
+__device__ __forceinline__ int seg_box(const NmsSegs &g, int b, int i) {
+  return g.order ? g.order[(size_t)b * g.stride + i] : b * g.stride + i;
+}
+// min_yx / min_z: the NMS_AUG_THICKNESS clamp of boxlist_nms_3d (dy, dx >= min_yx, dz >= min_z, IoU only)
+__global__ void k_nms_prep(const float *__restrict__ boxes, NmsSegs g, float min_yx, float min_z,
+                           NmsBox *__restrict__ rec) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, sb = blockIdx.y;
+  if (i >= seg_count(g, sb)) return;
+  const float *b = boxes + (size_t)seg_box(g, sb, i) * 7;
+  const float d0 = fmaxf(b[3], min_yx), d1 = fmaxf(b[4], min_yx), dz = fmaxf(b[5], min_z);
   NmsBox r;
-  r.d0 = b[3]; r.d1 = b[4];
-  r.z0 = b[2]; r.z1 = b[2] + b[5];
-  r.raw[0] = b[0]; r.raw[1] = b[1]; r.raw[2] = b[3]; r.raw[3] = b[4]; r.raw[4] = b[6];
-  r.q = make_quad(b[0], b[1], b[3], b[4], b[6]);
-  r.radius = 0.5f * sqrtf(b[3] * b[3] + b[4] * b[4]);
+  r.d0 = d0; r.d1 = d1;
+  r.z0 = b[2]; r.z1 = b[2] + dz;
+  r.raw[0] = b[0]; r.raw[1] = b[1]; r.raw[2] = d0; r.raw[3] = d1; r.raw[4] = b[6];
+  r.q = make_quad(b[0], b[1], d0, d1, b[6]);
+  r.radius = 0.5f * sqrtf(d0 * d0 + d1 * d1);
   r.area = quad_area_f64(r.q.p);
-  rec[i] = r;
+  rec[(size_t)sb * g.n_max + i] = r;
 }
 // Suppression masks in two passes so that the expensive geometry runs with full lanes:
 //  k_nms_pairs  -- 256 threads per 64 x 64 tile (wave w: rows 16w..16w+15, lanes = candidate boxes j):
@@ -328,10 +343,13 @@ __global__ void k_nms_prep(const float *__restrict__ boxes, int n, NmsBox *__res
 //                     the other box, no edges cross -> area 0 -> gate false.
 //  k_nms_eval   -- one thread per listed pair: gate (fp32 IoU of nms_gpu.py x z IoU) and fp64 polygon IoU
 //                  >= thresh; sets bit j of word [i][j/64] (atomicOr, order independent).
-__global__ __launch_bounds__(256) void k_nms_pairs(const NmsBox *__restrict__ rec, int n, int2 *__restrict__ pairs,
+static constexpr int kNmsIdxBits = 12;  // candidates per segment <= 4096
+__global__ __launch_bounds__(256) void k_nms_pairs(const NmsBox *__restrict__ rec, NmsSegs g, int2 *__restrict__ pairs,
                                                    unsigned int *__restrict__ n_pairs) {
-  const int rt = blockIdx.y, ct = blockIdx.x;
-  if (ct < rt) return;
+  const int rt = blockIdx.y, ct = blockIdx.x, sb = blockIdx.z;
+  const int n = seg_count(g, sb);
+  if (ct < rt || ct * 64 >= n) return;
+  rec += (size_t)sb * g.n_max;
   __shared__ NmsBox srow[64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x < 64 && rt * 64 + threadIdx.x < n) srow[threadIdx.x] = rec[rt * 64 + threadIdx.x];
@@ -356,17 +374,19 @@ __global__ __launch_bounds__(256) void k_nms_pairs(const NmsBox *__restrict__ re
       unsigned int base = 0;
       if (lane == 0) base = atomicAdd(n_pairs, (unsigned int)__popcll(bal));
       base = __shfl(base, 0, 64);
-      if (cand) pairs[base + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2(i, j);
+      if (cand) pairs[base + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2((sb << kNmsIdxBits) | i, j);
     }
   }
 }
 __global__ __launch_bounds__(256) void k_nms_eval(const NmsBox *__restrict__ rec, const int2 *__restrict__ pairs,
-                                                  const unsigned int *__restrict__ n_pairs, int ncb, float thresh,
-                                                  unsigned long long *__restrict__ mask) {
+                                                  const unsigned int *__restrict__ n_pairs, int n_max, int ncb,
+                                                  float thresh, unsigned long long *__restrict__ mask) {
   const unsigned int total = *n_pairs;
   for (unsigned int p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
-    const int2 ij = pairs[p];
-    const NmsBox rb = rec[ij.x], cb = rec[ij.y];
+    int2 ij = pairs[p];
+    const size_t seg0 = (size_t)(ij.x >> kNmsIdxBits) * n_max;  // first record / mask row of the segment
+    ij.x &= (1 << kNmsIdxBits) - 1;
+    const NmsBox rb = rec[seg0 + ij.x], cb = rec[seg0 + ij.y];
     // gate = boxes_iou_3d(dets, dets)[i, j] > 0 (nms_cpu.py:35, spconv nms.h)
     float v = iou_eval(cb.q, cb.d0, cb.d1, rb.q, rb.d0, rb.d1, -1);
     bool same = true;
@@ -381,29 +401,34 @@ __global__ __launch_bounds__(256) void k_nms_eval(const NmsBox *__restrict__ rec
     if (!(ia > 0)) continue;
     const double ua = rb.area + cb.area - ia;
     if (ua > 0 && ia / ua >= (double)thresh)
-      atomicOr(&mask[(size_t)ij.x * ncb + (ij.y >> 6)], 1ull << (ij.y & 63));
+      atomicOr(&mask[(seg0 + ij.x) * ncb + (ij.y >> 6)], 1ull << (ij.y & 63));
   }
 }
 // Greedy sweep by ONE wave: lane w owns word w of the "removed" bit vector.  Per 64-box chunk the
 // intra-chunk chain is resolved on the diagonal words with v_readlane; the chunk's 64 mask rows are
 // loaded unconditionally in one batch (independent loads) and OR-ed in for the kept boxes; the next
 // chunk's diagonal word is fetched one chunk ahead.
-__global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long *__restrict__ mask, int n,
-                                                  int ncb, int max_keep, int32_t *__restrict__ keep,
+__global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long *__restrict__ mask, NmsSegs g, int ncb,
+                                                  int max_keep, int32_t *__restrict__ keep,
                                                   int32_t *__restrict__ n_keep) {
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x, sb = blockIdx.x;
+  const int n = seg_count(g, sb);
+  mask += (size_t)sb * g.n_max * ncb;  // rows of ncb words; this segment uses the first ceil(n/64)
+  keep += (size_t)sb * g.n_max;
+  n_keep += sb;
+  const int ncw = (n + 63) / 64;
   unsigned long long removed = 0;  // word `lane`
   int cnt = 0;
   unsigned long long diag_next = (lane < min(64, n)) ? mask[(size_t)lane * ncb] : 0ull;
-  for (int c = 0; c < ncb && cnt < max_keep; c++) {   // the caller keeps at most max_keep survivors
+  for (int c = 0; c < ncw && cnt < max_keep; c++) {   // the caller keeps at most max_keep survivors
     const int base = c * 64;
     const int nrow = min(64, n - base);
     const unsigned long long diag = diag_next;
-    if (c + 1 < ncb) {
+    if (c + 1 < ncw) {
       const int nr2 = min(64, n - base - 64);
       diag_next = (lane < nr2) ? mask[(size_t)(base + 64 + lane) * ncb + c + 1] : 0ull;
     }
-    const bool mine = lane > c && lane < ncb;  // words left of the diagonal are never read again
+    const bool mine = lane > c && lane < ncw;  // words left of the diagonal are never read again
     unsigned long long w[64];
 #pragma unroll
     for (int b = 0; b < 64; b++) w[b] = (mine && b < nrow) ? mask[(size_t)(base + b) * ncb + lane] : 0ull;
@@ -427,7 +452,7 @@ __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long *__re
     while (k) {
       const int b = __builtin_ctzll(k);
       k &= k - 1;
-      if (lane == 0) keep[cnt] = base + b;
+      if (lane == 0) keep[cnt] = seg_box(g, sb, base + b);
       cnt++;
     }
   }
@@ -497,37 +522,49 @@ int d3d_boxes_iou_3d(const float *targets, int M, const float *anchors, int N, c
   return D3D_OK;
 }
 
-size_t d3d_nms_scratch_bytes(int n) {
-  size_t ncb = ((size_t)n + 63) / 64;
-  return (size_t)n * ncb * 8 + (size_t)n * sizeof(NmsBox) + ((size_t)n * n / 2 + 64) * sizeof(int2) + 2048;
+size_t d3d_nms_batched_scratch_bytes(int segments, int n_max) {
+  const size_t B = segments > 0 ? segments : 0, n = n_max > 0 ? n_max : 0, ncb = (n + 63) / 64;
+  return B * n * ncb * 8 + B * n * sizeof(NmsBox) + (B * n * n / 2 + 64) * sizeof(int2) + 2048;
+}
+size_t d3d_nms_scratch_bytes(int n) { return d3d_nms_batched_scratch_bytes(1, n); }
+
+int d3d_rotate_nms_3d_batched(const float *boxes, const int32_t *order, int stride, const int32_t *counts,
+                              int segments, int n_max, float thresh, float min_yx, float min_z, int max_keep,
+                              int32_t *keep, int32_t *n_keep, void *scratch, size_t scratch_bytes, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int B = segments, n = n_max;
+  D3D_REQUIRE(n >= 0 && n <= (1 << kNmsIdxBits), "rotate_nms_3d: n_max=%d out of range (<= 4096)", n);
+  D3D_REQUIRE(B >= 0 && B <= 4096 && n_keep, "rotate_nms_3d: bad segment count %d or null n_keep", B);
+  if (B == 0) return D3D_OK;
+  if (n == 0) {
+    D3D_HIP_CHECK(hipMemsetAsync(n_keep, 0, sizeof(int32_t) * B, s));
+    return D3D_OK;
+  }
+  D3D_REQUIRE(boxes && keep && scratch && scratch_bytes >= d3d_nms_batched_scratch_bytes(B, n), "rotate_nms_3d: bad buffers");
+  D3D_REQUIRE(B == 1 || order || stride >= n, "rotate_nms_3d: overlapping segments (stride %d < n_max %d)", stride, n);
+  const int ncb = (n + 63) / 64;
+  char *base = (char *)scratch;
+  unsigned long long *mask = (unsigned long long *)base;
+  size_t off = ((size_t)B * n * ncb * 8 + 255) & ~size_t(255);
+  unsigned int *n_pairs = (unsigned int *)(base + off);
+  off += 256;
+  NmsBox *rec = (NmsBox *)(base + off);
+  off = (off + (size_t)B * n * sizeof(NmsBox) + 255) & ~size_t(255);
+  int2 *pairs = (int2 *)(base + off);
+  const NmsSegs g = {order, counts, stride, n};
+  D3D_HIP_CHECK(hipMemsetAsync(mask, 0, (((size_t)B * n * ncb * 8 + 255) & ~size_t(255)) + 256, s));  // masks + pair counter
+  hipLaunchKernelGGL(k_nms_prep, dim3((n + 127) / 128, B), dim3(128), 0, s, boxes, g, min_yx, min_z, rec);
+  hipLaunchKernelGGL(k_nms_pairs, dim3(ncb, ncb, B), dim3(256), 0, s, rec, g, pairs, n_pairs);
+  hipLaunchKernelGGL(k_nms_eval, dim3(512), dim3(256), 0, s, rec, pairs, n_pairs, n, ncb, thresh, mask);
+  hipLaunchKernelGGL(k_nms_sweep, dim3(B), dim3(64), 0, s, mask, g, ncb, max_keep > 0 ? max_keep : n, keep, n_keep);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
 }
 
 int d3d_rotate_nms_3d_sorted(const float *boxes, int n, float thresh, int max_keep, int32_t *keep,
                              int32_t *n_keep, void *scratch, size_t scratch_bytes, void *stream) {
-  hipStream_t s = (hipStream_t)stream;
-  D3D_REQUIRE(n >= 0 && n <= 4096, "rotate_nms_3d: n=%d out of range (<= 4096)", n);
-  D3D_REQUIRE(n_keep, "rotate_nms_3d: null n_keep");
-  if (n == 0) {
-    D3D_HIP_CHECK(hipMemsetAsync(n_keep, 0, sizeof(int32_t), s));
-    return D3D_OK;
-  }
-  D3D_REQUIRE(boxes && keep && scratch && scratch_bytes >= d3d_nms_scratch_bytes(n), "rotate_nms_3d: bad buffers");
-  const int ncb = (n + 63) / 64;
-  char *base = (char *)scratch;
-  unsigned long long *mask = (unsigned long long *)base;
-  size_t off = ((size_t)n * ncb * 8 + 255) & ~size_t(255);
-  unsigned int *n_pairs = (unsigned int *)(base + off);
-  off += 256;
-  NmsBox *rec = (NmsBox *)(base + off);
-  off = (off + (size_t)n * sizeof(NmsBox) + 255) & ~size_t(255);
-  int2 *pairs = (int2 *)(base + off);
-  D3D_HIP_CHECK(hipMemsetAsync(mask, 0, (size_t)n * ncb * 8 + 256 + 256, s));   // masks + pair counter
-  hipLaunchKernelGGL(k_nms_prep, dim3((n + 127) / 128), dim3(128), 0, s, boxes, n, rec);
-  hipLaunchKernelGGL(k_nms_pairs, dim3(ncb, ncb), dim3(256), 0, s, rec, n, pairs, n_pairs);
-  hipLaunchKernelGGL(k_nms_eval, dim3(512), dim3(256), 0, s, rec, pairs, n_pairs, ncb, thresh, mask);
-  hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(64), 0, s, mask, n, ncb, max_keep > 0 ? max_keep : n, keep, n_keep);
-  D3D_LAUNCH_CHECK();
-  return D3D_OK;
+  return d3d_rotate_nms_3d_batched(boxes, nullptr, 0, nullptr, 1, n, thresh, 0.f, 0.f, max_keep, keep, n_keep, scratch,
+                                   scratch_bytes, stream);
 }
 
 int d3d_box_decode(const float *enc, const float *anchors, int n, const float *weights_host,

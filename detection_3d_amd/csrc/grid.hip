@@ -493,6 +493,27 @@ __global__ void k_locations(const int32_t *__restrict__ loc, int n, int64_t *__r
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n * 4) out[t] = loc[t];
 }
+// AnchorGenerator for one map: site i, cell anchor a -> (loc_i / voxel_scale * stride + base_a.xyz, base_a.size, yaw)
+struct AnchorBase {
+  float v[16 * 7];
+};
+__global__ void k_anchors(const int32_t *__restrict__ loc, int n, int A, AnchorBase base, float vs, float s0, float s1,
+                          float s2, float *__restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * A) return;
+  const int i = t / A, a = t - i * A;
+  const int32_t *p = loc + (size_t)i * 4;
+  const float *b = base.v + a * 7;
+  float *o = out + (size_t)t * 7;
+  // true division first, then the stride (anchor_generator_sparse3d.py:99), then + base (x + 0 keeps x)
+  o[0] = (float)p[0] / vs * s0 + b[0];
+  o[1] = (float)p[1] / vs * s1 + b[1];
+  o[2] = (float)p[2] / vs * s2 + b[2];
+  o[3] = 0.f + b[3];
+  o[4] = 0.f + b[4];
+  o[5] = 0.f + b[5];
+  o[6] = 0.f + b[6];
+}
 __global__ void k_sparse_to_dense(const float *__restrict__ in, int planes,
                                   const int32_t *__restrict__ loc, int n, int sx, int sy, int sz,
                                   float *__restrict__ out) {
@@ -796,6 +817,25 @@ int d3d_get_spatial_locations(d3d_meta *m, const int *size, int64_t *out, void *
   if (g->n == 0) return D3D_OK;
   D3D_REQUIRE(out, "null output");
   hipLaunchKernelGGL(k_locations, grid1d((long)g->n * 4), dim3(256), 0, s, g->loc, g->n, out);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+int d3d_anchors(d3d_meta *m, const int *size, const float *base_host, int A, const float *stride_host,
+                float voxel_scale, float *out, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(m && size && base_host && stride_host && A >= 1 && A <= 16 && voxel_scale > 0, "anchors: bad arguments");
+  Grid *g = find_grid(m, size);
+  if (!g) {
+    set_error("anchors: no grid of spatial size [%d,%d,%d]", size[0], size[1], size[2]);
+    return D3D_ERR_STATE;
+  }
+  if (g->n == 0) return D3D_OK;
+  D3D_REQUIRE(out, "null output");
+  AnchorBase base;
+  for (int i = 0; i < A * 7; i++) base.v[i] = base_host[i];
+  hipLaunchKernelGGL(k_anchors, grid1d((long)g->n * A), dim3(256), 0, s, g->loc, g->n, A, base, voxel_scale,
+                     stride_host[0], stride_host[1], stride_host[2], out);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }

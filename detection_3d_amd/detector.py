@@ -103,6 +103,19 @@ class AnchorGenerator(nn.Module):
     def num_anchors_per_location(self):
         return self.anchor_num_per_loc
 
+    def forward_cat(self, feature_maps_sparse):
+        """torch.cat(self(feature_maps_sparse), 0) written in place by one d3d_anchors launch per map."""
+        A = self.anchor_num_per_loc
+        ns = [f.features.shape[0] for f in feature_maps_sparse]
+        out = torch.empty((sum(ns) * A, 7), dtype=torch.float32, device=feature_maps_sparse[0].features.device)
+        o = 0
+        for base, fmap, stride, n in zip(self.cell_anchors, feature_maps_sparse, self.strides, ns):
+            if n:
+                fmap.metadata.anchors(fmap.spatial_size, base.tolist(), stride.tolist(), self.voxel_scale,
+                                      out[o * A:(o + n) * A])
+            o += n
+        return out
+
     def forward(self, feature_maps_sparse):
         anchors = []
         for base, fmap, stride in zip(self.cell_anchors, feature_maps_sparse, self.strides):
@@ -140,6 +153,11 @@ class RPNHead(nn.Module):
     def forward(self, features):
         """features: list of [n_s, C]  ->  objectness [sum n_s*A], regression [sum n_s*A, 7] in the
         flattening order of cat_scales_obj_reg (:19-77): scale, site, anchor."""
+        if not torch.is_grad_enabled() and len(features) > 1:
+            # the head is shared by the scales and acts per site: one GEMM over the concatenated sites
+            t = F.relu(self._lin(self.conv, torch.cat(features, 0)))
+            return (self._lin(self.cls_logits, t).reshape(-1, self.seperate_rpn),
+                    self._lin(self.bbox_pred, t).reshape(-1, 7 * self.seperate_rpn))
         obj, reg = [], []
         for f in features:
             t = F.relu(self._lin(self.conv, f))
@@ -171,8 +189,8 @@ class RPNModule(nn.Module):
         k = min(pre, scores.shape[0])
         scores_k, idx = scores.topk(k, dim=0, sorted=True)                      # inference_3d.py:109
         proposals = box_ops.box_decode(box_regression[idx], anchors[idx])       # :123
-        keep = box_ops.nms_3d_clamped(proposals, scores_k, self.nms_thresh, self.nms_aug_thickness,
-                                      max_proposals=post, flag='rpn_post')
+        keep = box_ops.nms_3d_presorted(proposals, self.nms_thresh, self.nms_aug_thickness, max_proposals=post,
+                                        flag='rpn_post')                        # scores_k is sorted: no re-sort
         return proposals[keep], scores_k[keep]
 
     def forward(self, features_sparse, targets=None):
@@ -180,7 +198,7 @@ class RPNModule(nn.Module):
         (rpn_sparse3d.py:233-270, rpn/inference_3d.py:53-80,180-199)."""
         objectness, box_regression = self.head([f.features for f in features_sparse])
         with torch.no_grad():
-            anchors = torch.cat(self.anchor_generator(features_sparse), 0)
+            anchors = self.anchor_generator.forward_cat(features_sparse)
         assert objectness.shape[0] == box_regression.shape[0] == anchors.shape[0]
         if self.sep.need_seperate and self.head.seperate_rpn > 1:
             return self._forward_grouped(anchors, objectness, box_regression, targets)
@@ -380,22 +398,23 @@ class PostProcessor(nn.Module):
         prob = F.softmax(class_logits, -1)
         boxes = box_ops.box_decode(box_regression, proposals, self.weights)     # [K, 7*nc]
         nc = prob.shape[1]
-        out_b, out_s, out_l = [], [], []
-        inds_all = prob > self.score_thresh
-        for j in range(1, nc):
-            inds = inds_all[:, j].nonzero().squeeze(1)
-            if inds.numel() == 0:
-                continue
-            sj = prob[inds, j]
-            bj = boxes[inds, j * 7:(j + 1) * 7].contiguous()
-            keep = box_ops.nms_3d_clamped(bj, sj, self.nms, self.nms_aug_thickness, -1, flag='roi_post')
-            out_b.append(bj[keep])
-            out_s.append(sj[keep])
-            out_l.append(torch.full((keep.numel(),), j, dtype=torch.int64, device=prob.device))
-        if not out_b:
+        K = prob.shape[0]
+        if nc < 2 or K == 0:
             z = prob.new_zeros
             return {"bbox3d": z((0, 7)), "scores": z((0,)), "labels": torch.zeros(0, dtype=torch.int64, device=prob.device)}
-        b, s, l = torch.cat(out_b), torch.cat(out_s), torch.cat(out_l)
+        # the per-class loop of inference.py:113-139 as ONE batched NMS: class j's candidates (prob > thresh) in
+        # descending score order (ties: lower RoI first) are a segment of box indices roi*nc + j
+        sc = prob[:, 1:].t().contiguous()                                        # [nc-1, K]
+        cand = sc > self.score_thresh
+        idx = torch.sort(torch.where(cand, sc, sc.new_full((), -1.0)), dim=1, descending=True, stable=True)[1]
+        order = (idx * nc + torch.arange(1, nc, device=prob.device).view(-1, 1)).to(torch.int32).contiguous()
+        counts = cand.sum(1).to(torch.int32)
+        n_max = min(K, 2000)                                                     # pre_max_size of rotate_nms_3d
+        keep, nk = box_ops.nms_3d_batched(boxes.view(-1, 7), order, counts, n_max, self.nms, self.nms_aug_thickness,
+                                          500)                                   # post_max_size (boxlist_ops_3d.py)
+        valid = torch.arange(keep.shape[1], device=prob.device).view(1, -1) < nk.view(-1, 1)
+        flat = keep[valid].long()                                                # class-major, selection order
+        b, s, l = boxes.view(-1, 7)[flat], prob.reshape(-1)[flat], flat % nc
         n = s.shape[0]
         if n > self.detections_per_img > 0:                                      # :140-148
             thresh = torch.kthvalue(s, n - self.detections_per_img + 1)[0]

@@ -151,6 +151,14 @@ class Metadata_3(object):
         check(lib().d3d_get_spatial_locations(self._h, ints(_size3(spatial_size)), ptr(out), stream_of()))
         return out
 
+    def anchors(self, spatial_size, base, stride, voxel_scale, out):
+        """d3d_anchors: fills out [nActive*A, 7] with the anchors of every active site of this map
+        (anchor_generator_sparse3d.py:86-120); base [A,7] and stride [3] are host sequences."""
+        base = [float(v) for row in base for v in row]
+        check(lib().d3d_anchors(self._h, ints(_size3(spatial_size)), _lib.floats(base), len(base) // 7,
+                                _lib.floats(stride), float(voxel_scale), ptr(out), stream_of()))
+        return out
+
     def arena_used(self):
         n = ctypes.c_size_t(0)
         check(lib().d3d_meta_arena_used(self._h, ctypes.byref(n)))

@@ -72,6 +72,12 @@ int d3d_input_layer_export(d3d_meta *m, int32_t *offsets, int32_t *idx, void *st
 int d3d_get_n_active(d3d_meta *m, const int *spatial_size_host, int *n_host);
 int d3d_get_spatial_locations(d3d_meta *m, const int *spatial_size_host, int64_t *out, void *stream);
 
+/* AnchorGenerator.forward for one feature map (modeling/rpn/anchor_generator_sparse3d.py:86-120): for active site i
+ * (in getSpatialLocations order) and cell anchor a < A (<= 16): out[(i*A + a)] = (loc_i / voxel_scale * stride, 0,0,0,0)
+ * + base[a], fp32 with the reference's operation order.  base_host [A,7], stride_host [3]; out [n_active*A, 7]. */
+int d3d_anchors(d3d_meta *m, const int *spatial_size_host, const float *base_host, int A,
+                const float *stride_host, float voxel_scale, float *out, void *stream);
+
 /* a4. Metadata::getSubmanifoldRuleBook (Metadata.cpp:430-443; SubmanifoldConvolutionRules.h:27-45).
  * Builds (or finds cached) the rulebook; *n_rules_host = number of (in,out) pairs.           */
 int d3d_subm_prepare(d3d_meta *m, const int *spatial_size_host, const int *filter_host,
@@ -235,6 +241,17 @@ int d3d_boxes_iou_3d(const float *targets, int M, const float *anchors, int N,
 int d3d_rotate_nms_3d_sorted(const float *boxes, int n, float thresh, int max_keep, int32_t *keep,
                              int32_t *n_keep, void *scratch, size_t scratch_bytes, void *stream);
 size_t d3d_nms_scratch_bytes(int n);
+/* The same sweep for `segments` independent candidate lists in one set of launches (the classes of
+ * roi_heads/box_head_3d/inference.py:113-139, or one list with its top-k order): candidate i of segment b is box
+ * order[b*stride + i] of boxes [*,7] (b*stride + i when order is NULL), i < counts[b] (device int32, NULL: n_max
+ * each, <= 4096), in descending score order.  min_yx / min_z: the NMS_AUG_THICKNESS clamp of boxlist_nms_3d
+ * (structures/boxlist_ops_3d.py:18-52) applied for the IoU only.  keep int32 [segments, n_max] receives the BOX
+ * indices of the survivors in selection order, n_keep int32 [segments] their number (<= max_keep when > 0).   */
+int d3d_rotate_nms_3d_batched(const float *boxes, const int32_t *order, int stride, const int32_t *counts,
+                              int segments, int n_max, float thresh, float min_yx, float min_z,
+                              int max_keep, int32_t *keep, int32_t *n_keep, void *scratch,
+                              size_t scratch_bytes, void *stream);
+size_t d3d_nms_batched_scratch_bytes(int segments, int n_max);
 /* a14. BoxCoder3D.decode (maskrcnn_benchmark/modeling/box_coder_3d.py:38-65). */
 int d3d_box_decode(const float *enc, const float *anchors, int n, const float *weights_host,
                    float clip, float *out, void *stream);

@@ -192,3 +192,34 @@ def test_nms_max_keep_is_prefix_of_full_sweep(dev, cap):
     nf, npart = int(nf), int(npart)
     assert npart == min(cap, nf)
     assert torch.equal(part[:npart], full[:npart])
+
+
+def test_nms_batched_segments_match_single_lists(dev):
+    """d3d_rotate_nms_3d_batched: ragged segments (incl. an empty one) addressed through `order`, size clamp in
+    the kernel; every segment must give the oracle's survivor list for its own boxes."""
+    from detection_3d_amd import box_ops
+    n_all, B = 900, 4
+    b, s = make_boxes(5, n_all)
+    rng = np.random.RandomState(0)
+    counts = np.array([700, 0, 333, 64], np.int32)
+    order = np.zeros((B, n_all), np.int32)
+    segs = []
+    for k in range(B):
+        sel = rng.permutation(n_all)[:counts[k]]
+        sel = sel[np.argsort(-s[sel], kind="stable")]
+        order[k, :counts[k]] = sel
+        order[k, counts[k]:] = rng.randint(0, n_all, n_all - counts[k])          # garbage past the count
+        segs.append(sel)
+    aug = (0.25, 0.35)
+    keep, nk = box_ops.nms_3d_batched(torch.from_numpy(b).to(dev), torch.from_numpy(order).to(dev),
+                                      torch.from_numpy(counts).to(dev), 800, 0.4, aug, 500)
+    keep, nk = keep.cpu().numpy(), nk.cpu().numpy()
+    bc = b.copy()
+    bc[:, 3:5] = np.maximum(bc[:, 3:5], aug[0])
+    bc[:, 5] = np.maximum(bc[:, 5], aug[1])
+    for k in range(B):
+        sel = segs[k]
+        want = sel[oracle.rotate_nms_3d(bc[sel], s[sel], 0.4)][:500] if len(sel) else np.zeros(0, np.int64)
+        assert nk[k] == len(want)
+        assert np.array_equal(keep[k, :nk[k]], want)
+    assert nk[0] < counts[0]

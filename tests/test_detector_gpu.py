@@ -57,6 +57,11 @@ def test_rpn_head_and_anchors(setup):
     assert torch.allclose(reg.cpu(), torch.cat(wr), rtol=1e-3, atol=1e-4)
     anchors = torch.cat(model.rpn.anchor_generator(mid["rpn_features"]), 0).cpu().numpy()
     assert np.array_equal(anchors, orc.anchors([l for _, l in maps]))
+    # the one-launch-per-map form (d3d_anchors) and the batched head are the inference path
+    assert np.array_equal(model.rpn.anchor_generator.forward_cat(mid["rpn_features"]).cpu().numpy(), anchors)
+    with torch.enable_grad():
+        obj_l, reg_l = model.rpn.head(feats)                                     # per-level GEMMs
+    assert torch.allclose(obj, obj_l.detach(), rtol=1e-4, atol=1e-5) and torch.allclose(reg, reg_l.detach(), rtol=1e-4, atol=1e-5)
     assert anchors.shape[0] == obj.shape[0] == 4 * sum(m[1].shape[0] for m in maps)
 
 
@@ -75,6 +80,8 @@ def test_rpn_decode_and_nms_exact(setup, dev):
     wkeep = nms_clamped(want, sk.cpu().numpy(), 0.5, [0.3, 0.3], 1000)
     assert np.array_equal(keep, wkeep)
     assert 10 < len(keep) < 2000
+    keep2 = box_ops.nms_3d_presorted(props, 0.5, [0.3, 0.3], max_proposals=1000, flag="rpn_post").cpu().numpy()
+    assert np.array_equal(keep2, wkeep)
     assert np.array_equal(mid["proposals"].cpu().numpy()[:, :3], want[wkeep][:, :3])
 
 
