@@ -358,10 +358,16 @@ __global__ __launch_bounds__(256) void k_nms_pairs(const NmsBox *__restrict__ re
   if (j < n) cb = rec[j];
   __syncthreads();
   const int nrow = min(64, n - rt * 64);
-  for (int ii = wave * 16; ii < min(nrow, wave * 16 + 16); ii++) {
+  // the wave's 16 rows first (ballots stay in registers), then ONE counter atomic per wave: the pair counter is
+  // a single address, and one atomic per (wave, row) serialises the whole grid on it
+  unsigned long long bal[16];
+  unsigned int total = 0;
+#pragma unroll
+  for (int u = 0; u < 16; u++) {
+    const int ii = wave * 16 + u;
     const int i = rt * 64 + ii;
     bool cand = false;
-    if (j < n && j > i) {
+    if (ii < nrow && j < n && j > i) {
       const NmsBox &rb = srow[ii];
       const float overlap = fminf(cb.z1, rb.z1) - fmaxf(cb.z0, rb.z0);
       const float dx = cb.raw[0] - rb.raw[0], dy = cb.raw[1] - rb.raw[1];
@@ -369,13 +375,19 @@ __global__ __launch_bounds__(256) void k_nms_pairs(const NmsBox *__restrict__ re
       cand = overlap > 0.f && dx * dx + dy * dy <= rr * rr &&
              !quads_separated(rb.q.p, cb.q.p, 1e-3f * (1.f + cb.radius + rb.radius));
     }
-    const unsigned long long bal = __ballot(cand);
-    if (bal) {
-      unsigned int base = 0;
-      if (lane == 0) base = atomicAdd(n_pairs, (unsigned int)__popcll(bal));
-      base = __shfl(base, 0, 64);
-      if (cand) pairs[base + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2((sb << kNmsIdxBits) | i, j);
-    }
+    bal[u] = __ballot(cand);
+    total += (unsigned int)__popcll(bal[u]);
+  }
+  if (total == 0) return;
+  unsigned int base = 0;
+  if (lane == 0) base = atomicAdd(n_pairs, total);
+  base = __shfl(base, 0, 64);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int u = 0; u < 16; u++) {
+    if ((bal[u] >> lane) & 1ull)
+      pairs[base + __popcll(bal[u] & lt)] = make_int2((sb << kNmsIdxBits) | (rt * 64 + wave * 16 + u), j);
+    base += (unsigned int)__popcll(bal[u]);
   }
 }
 __global__ __launch_bounds__(256) void k_nms_eval(const NmsBox *__restrict__ rec, const int2 *__restrict__ pairs,
@@ -417,21 +429,28 @@ __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long *__re
   keep += (size_t)sb * g.n_max;
   n_keep += sb;
   const int ncw = (n + 63) / 64;
+  const unsigned long long lt = (1ull << lane) - 1ull;
   unsigned long long removed = 0;  // word `lane`
   int cnt = 0;
-  unsigned long long diag_next = (lane < min(64, n)) ? mask[(size_t)lane * ncb] : 0ull;
-  for (int c = 0; c < ncw && cnt < max_keep; c++) {   // the caller keeps at most max_keep survivors
+  // rows of chunk c, word `lane` (words left of the diagonal are never read again)
+  auto load_rows = [&](int c, unsigned long long *w) {
     const int base = c * 64;
+    const bool mine = c < ncw && lane > c && lane < ncw;
     const int nrow = min(64, n - base);
-    const unsigned long long diag = diag_next;
-    if (c + 1 < ncw) {
-      const int nr2 = min(64, n - base - 64);
-      diag_next = (lane < nr2) ? mask[(size_t)(base + 64 + lane) * ncb + c + 1] : 0ull;
-    }
-    const bool mine = lane > c && lane < ncw;  // words left of the diagonal are never read again
-    unsigned long long w[64];
 #pragma unroll
     for (int b = 0; b < 64; b++) w[b] = (mine && b < nrow) ? mask[(size_t)(base + b) * ncb + lane] : 0ull;
+  };
+  auto load_diag = [&](int c) -> unsigned long long {
+    const int base = c * 64;
+    return (c < ncw && lane < min(64, n - base)) ? mask[(size_t)(base + lane) * ncb + c] : 0ull;
+  };
+  // one chunk: `w` holds its rows, `diag` its diagonal word; the NEXT chunk's rows and diagonal are requested
+  // before the dependent chain so that their latency hides under it
+  auto step = [&](int c, const unsigned long long *w, unsigned long long *w_next, unsigned long long &diag) {
+    const int base = c * 64;
+    const int nrow = min(64, n - base);
+    load_rows(c + 1, w_next);
+    const unsigned long long diag_next = load_diag(c + 1);
     unsigned long long alive = ~__shfl(removed, c, 64);
     if (nrow < 64) alive &= (1ull << nrow) - 1ull;
     unsigned long long kept = 0;
@@ -448,13 +467,20 @@ __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long *__re
 #pragma unroll
     for (int b = 0; b < 64; b++)
       if ((kept >> b) & 1ull) removed |= w[b];
-    unsigned long long k = kept;
-    while (k) {
-      const int b = __builtin_ctzll(k);
-      k &= k - 1;
-      if (lane == 0) keep[cnt] = seg_box(g, sb, base + b);
-      cnt++;
+    // survivors of the chunk, all lanes at once
+    if ((kept >> lane) & 1ull) {
+      const int pos = cnt + __popcll(kept & lt);
+      if (pos < g.n_max) keep[pos] = seg_box(g, sb, base + lane);
     }
+    cnt += __popcll(kept);
+    diag = diag_next;
+  };
+  unsigned long long wa[64], wb[64];
+  unsigned long long diag = load_diag(0);
+  load_rows(0, wa);
+  for (int c = 0; c < ncw && cnt < max_keep; c += 2) {   // the caller keeps at most max_keep survivors
+    step(c, wa, wb, diag);
+    if (c + 1 < ncw && cnt < max_keep) step(c + 1, wb, wa, diag);
   }
   if (lane == 0) *n_keep = min(cnt, max_keep);  // the last chunk may overshoot the cap
 }

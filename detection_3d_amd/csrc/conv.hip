@@ -58,27 +58,33 @@ __global__ void k_pack_weight(const float *__restrict__ w, int fv, int cin, int 
 
 // CT   = Cin tile staged in LDS per step (multiple of 8, <= 128); NCT tiles cover Cin
 // NT   = 32-column accumulator tiles per wave; a row block is shared by WPBLK = COUT/32/NT waves
-// BPW  = row blocks per workgroup (only with WPBLK == 1, where waves never synchronise)
-template <int CT, int NCT, int COUT, int NT, int BPW>
+// BPW  = row groups per workgroup (only with WPBLK == 1, where waves never synchronise)
+// MT   = 32-row blocks per wave ("row group"): the B fragments of a step (packed weights, re-fetched from
+//        L2 by every wave) are used for MT * 32 rows, which divides the dominant L2 -> L1 traffic by MT
+// VEC  = Cin equals the padded CT * NCT (16-byte row pieces): branch-free gather
+template <int CT, int NCT, int COUT, int NT, int BPW, int MT, bool VEC>
 __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
     const float *__restrict__ in, int cin, const float *__restrict__ wp,
     const int32_t *__restrict__ nbrT, int npos, const int32_t *__restrict__ rows,
     const uint32_t *__restrict__ blkmask, int n_blk, const float *__restrict__ residual,
     float *__restrict__ out, int n_split, float *__restrict__ partial, BnPre pre) {
   constexpr int WPBLK = COUT / 32 / NT;
-  static_assert(WPBLK == 1 || BPW == 1, "row blocks sharing a workgroup must be single-wave");
-  constexpr int TPB = WPBLK * 64;  // threads working on one row block
+  static_assert(WPBLK == 1 || BPW == 1, "row groups sharing a workgroup must be single-wave");
+  static_assert(MT == 1 || BPW == 1, "multi-block row groups take a whole workgroup");
+  constexpr int TPB = WPBLK * 64;  // threads working on one row group
   constexpr int LDA = CT + 4;      // +4 dwords: conflict-free ds_read_b128 of 32 rows
   constexpr int CP = CT * NCT;
   constexpr int LPR = CT / 4;      // threads per gathered row (16 B each)
   constexpr int RPP = TPB / LPR;   // rows per gather pass
-  constexpr int NIT = (32 / RPP) > 0 ? (32 / RPP) : 1;
-  __shared__ __attribute__((aligned(16))) float smem[BPW * 32 * LDA];
+  constexpr int GR = 32 * MT;      // rows of a group
+  constexpr int NIT = (GR / RPP) > 0 ? (GR / RPP) : 1;
+  __shared__ __attribute__((aligned(16))) float smem[BPW * GR * LDA];
 
   const int slot = threadIdx.x / TPB, tib = threadIdx.x % TPB;
-  const int blk = blockIdx.x * BPW + slot;
-  if (blk >= n_blk) return;  // BPW > 1 only when waves are independent (no barrier below)
-  float *As = smem + slot * 32 * LDA;
+  const int grp = blockIdx.x * BPW + slot;
+  const int blk0 = grp * MT;  // first 32-row block of the group
+  if (blk0 >= n_blk) return;  // BPW > 1 only when waves are independent (no barrier below)
+  float *As = smem + slot * GR * LDA;
   const int lane = tib & 63, wib = tib >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int grow = tib / LPR, gc4 = tib % LPR;
@@ -91,7 +97,13 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
       __syncthreads();
   };
 
-  uint32_t mask = blkmask[blk];
+  uint32_t sub[MT];  // active offsets of each 32-row block of the group
+  uint32_t mask = 0;
+#pragma unroll
+  for (int m = 0; m < MT; m++) {
+    sub[m] = blk0 + m < n_blk ? blkmask[blk0 + m] : 0u;
+    mask |= sub[m];
+  }
   if (n_split > 1) {
     // offset-split launch (few rows): this workgroup keeps every n_split-th active offset and
     // writes a partial tile; k_conv_reduce sums the partials in a fixed order.
@@ -101,16 +113,25 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
       if (ord % n_split == (int)blockIdx.y) keep |= m & (~m + 1);
     mask = keep;
   }
-  const int rowid = rows[blk * 32 + r];
-  f32x16 acc[NT];
+  int rowid[MT];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; nt++)
+  for (int m = 0; m < MT; m++) {
+    rowid[m] = blk0 + m < n_blk ? rows[(blk0 + m) * 32 + r] : -1;
 #pragma unroll
-    for (int i = 0; i < 16; i++) acc[nt][i] = 0.f;
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[m][nt][i] = 0.f;
+  }
 
-  const bool vec = (cin == CP);
-  const int32_t *nb = nbrT + blk * 32;
-  // register-staged gather of (offset k, Cin tile ct): issued one step ahead of its use
+  const int p0 = blk0 * 32;  // first plan position of the group
+  const int32_t *nb = nbrT + p0;
+  // Gather of (offset k, Cin tile ct) in two independent waves of loads, both issued ahead of their use:
+  //   load_idx(k)   : the NIT input-row indices this thread needs for offset k   (one step before issue_data)
+  //   issue_data(ct): the 16-byte row pieces, branch-free -- an absent neighbour reads row 0 and is zeroed
+  //                   at commit time (stage_real), so that no load waits for another one
+  //   commit_gather : registers -> LDS (+ the fused BatchNorm), after the previous step's MFMAs
+  int idx[NIT];
   f32x4 stage[NIT];
   // optional fused BatchNorm + leaky ReLU of the producer layer (y = leaky(x*w + b), applied to real rows
   // only: a missing neighbour contributes zeros, as a zero row of the normalised tensor would not);
@@ -130,47 +151,55 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
       bnb[t] = -mu * bnw[t] + be;
     }
   }
-  uint32_t stage_real = 0;  // bit it: stage[it] holds a real row (BatchNorm applies)
+  uint32_t stage_real = 0;  // bit it: stage[it] holds a real row
   int stage_ct = 0;
-  auto issue_gather = [&](int k, int ct) {
+  uint32_t idx_on = 0;  // bit it: idx[it] is a real plan entry (the loaded value is not touched before use)
+  auto load_idx = [&](int k) {
+    idx_on = 0;
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int row = it * RPP + grow;
+      const int mb = (32 % RPP == 0) ? (it * RPP) / 32 : (row >> 5);  // compile-time when a pass stays in one block
+      const bool on = row < GR && p0 + row < npos && ((sub[mb < MT ? mb : 0] >> k) & 1u);
+      idx[it] = nb[(size_t)k * npos + (on ? row : 0)];
+      idx_on |= (on ? 1u : 0u) << it;
+    }
+  };
+  auto issue_data = [&](int ct) {
     stage_real = 0;
     stage_ct = ct;
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
-      const int row = it * RPP + grow;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < 32) {
-        const int s = nb[(size_t)k * npos + row];
-        if (s >= 0) {
-          const float *p = in + (size_t)s * cin + ct * CT + gc4 * 4;
-          if (vec) {
-            v = *(const f32x4 *)p;
-            stage_real |= 1u << it;
-          } else {
-            const int c = ct * CT + gc4 * 4;
-            if (c + 0 < cin) v[0] = p[0];
-            if (c + 1 < cin) v[1] = p[1];
-            if (c + 2 < cin) v[2] = p[2];
-            if (c + 3 < cin) v[3] = p[3];
-          }
-        }
+      const int s = ((idx_on >> it) & 1u) ? idx[it] : -1;
+      const float *p = in + (size_t)(s < 0 ? 0 : s) * cin + ct * CT + gc4 * 4;
+      if (s >= 0) stage_real |= 1u << it;
+      if constexpr (VEC) {
+        stage[it] = *(const f32x4 *)p;
+      } else {
+        const int c = ct * CT + gc4 * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c + 0 < cin) v[0] = p[0];
+        if (c + 1 < cin) v[1] = p[1];
+        if (c + 2 < cin) v[2] = p[2];
+        if (c + 3 < cin) v[3] = p[3];
+        stage[it] = v;
       }
-      stage[it] = v;
     }
   };
   auto commit_gather = [&]() {
-    // the normalisation runs here, after the previous step's MFMAs, so that the gather loads stay in flight
     const f32x4 bw = stage_ct == 0 ? bnw[0] : bnw[NCT - 1], bb = stage_ct == 0 ? bnb[0] : bnb[NCT - 1];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
       const int row = it * RPP + grow;
       f32x4 v = stage[it];
-      if (pre.mean && ((stage_real >> it) & 1u)) {
+      if (pre.mean) {
         v = v * bw + bb;
 #pragma unroll
         for (int j = 0; j < 4; j++) v[j] = v[j] * ((v[j] > 0) ? 1.f : pre.leak);
       }
-      if (row < 32) *(f32x4 *)(As + row * LDA + gc4 * 4) = v;
+      v = ((stage_real >> it) & 1u) ? v : zero;
+      if (row < GR) *(f32x4 *)(As + row * LDA + gc4 * 4) = v;
     }
   };
 
@@ -189,11 +218,21 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
         dst[q * NT + nt] = *(const f32x4 *)(wk + ((size_t)(2 * q + h) * COUT + nt * 32 + r) * 4);
   };
 
+  // step tokens: (offset k, Cin tile ct) in increasing (k, ct) order over the active offsets
+  auto next_k = [&](int k) -> int {
+    const uint32_t m = k >= 31 ? 0u : (mask & ~((2u << k) - 1u));
+    return m ? __builtin_ctz(m) : -1;
+  };
   int k = mask ? __builtin_ctz(mask) : -1;
   int ct = 0;
+  int k_idx = -1;  // offset whose indices `idx` holds (or is loading)
   if (k >= 0) {
-    issue_gather(k, 0);
+    load_idx(k);
+    issue_data(0);
     if constexpr (PREB) load_b(bcur, k, 0);
+    // indices of the step after this one
+    k_idx = NCT > 1 ? k : next_k(k);
+    if (k_idx >= 0 && k_idx != k) load_idx(k_idx);
   }
   while (k >= 0) {
     commit_gather();
@@ -202,18 +241,19 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
     int nk = k, nct = ct + 1;
     if (nct == NCT) {
       nct = 0;
-      mask &= mask - 1;
-      nk = mask ? __builtin_ctz(mask) : -1;
+      nk = next_k(k);
     }
     if (nk >= 0) {
-      issue_gather(nk, nct);  // loads fly while the matrix cores work
+      issue_data(nct);  // loads fly while the matrix cores work; idx holds offset nk
       if constexpr (PREB) load_b(bnext, nk, nct);
+      // the step after that: its indices are requested now
+      const int k2 = (nct + 1 < NCT) ? nk : next_k(nk);
+      if (k2 >= 0 && k2 != nk) load_idx(k2);
     }
-    // ---- 32 x (NT*32) += A[32 x CT] * W[k][CT x cols] ----
+    // ---- (MT*32) x (NT*32) += A[MT*32 x CT] * W[k][CT x cols] ----
     const float *wk = wp + ((size_t)(k * (CP / 4) + ct * (CT / 4)) * COUT + colbase) * 4;
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
-      const f32x4 a = *(const f32x4 *)(As + r * LDA + q * 8 + h * 4);
       f32x4 b[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; nt++) {
@@ -223,15 +263,23 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
           b[nt] = *(const f32x4 *)(wk + ((size_t)(2 * q + h) * COUT + nt * 32 + r) * 4);
       }
 #pragma unroll
-      for (int nt = 0; nt < NT; nt++) {
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[nt][0], acc[nt], 0, 0, 0);
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[nt][1], acc[nt], 0, 0, 0);
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[nt][2], acc[nt], 0, 0, 0);
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[nt][3], acc[nt], 0, 0, 0);
+      for (int m = 0; m < MT; m++) {
+        if (MT > 1 && !((sub[m] >> k) & 1u)) continue;  // wave-uniform: this block has no rule at offset k
+        const f32x4 a = *(const f32x4 *)(As + (m * 32 + r) * LDA + q * 8 + h * 4);
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[nt][0], acc[m][nt], 0, 0, 0);
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[nt][1], acc[m][nt], 0, 0, 0);
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[nt][2], acc[m][nt], 0, 0, 0);
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[nt][3], acc[m][nt], 0, 0, 0);
+        }
       }
     }
     block_sync();
     if constexpr (PREB) {
+      // keep the register copy (and the wait for the prefetched fragments it implies) behind the MFMAs: the
+      // scheduler otherwise interleaves it with them and the loads issued above are waited for at once
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < NQ * NT; i++) bcur[i] = bnext[i];
     }
@@ -240,26 +288,40 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
   }
   // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
   if (n_split > 1) {
-    float *pt = partial + ((size_t)blockIdx.y * npos + (size_t)blk * 32) * COUT;
+    if constexpr (MT == 1) {
+      float *pt = partial + ((size_t)blockIdx.y * npos + (size_t)blk0 * 32) * COUT;
 #pragma unroll
-    for (int reg = 0; reg < 16; reg++) {
-      const int row_in = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      for (int reg = 0; reg < 16; reg++) {
+        const int row_in = (reg & 3) + 8 * (reg >> 2) + 4 * h;
 #pragma unroll
-      for (int nt = 0; nt < NT; nt++) pt[(size_t)row_in * COUT + colbase + nt * 32 + r] = acc[nt][reg];
+        for (int nt = 0; nt < NT; nt++) pt[(size_t)row_in * COUT + colbase + nt * 32 + r] = acc[0][nt][reg];
+      }
     }
     return;
   }
 #pragma unroll
-  for (int reg = 0; reg < 16; reg++) {
-    const int row_in = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-    const int orow = __shfl(rowid, row_in, 64);
-    if (orow < 0) continue;
+  for (int m = 0; m < MT; m++) {
+    int orow[16];
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-      const size_t o = (size_t)orow * COUT + colbase + nt * 32 + r;
-      float v = acc[nt][reg];
-      if (residual) v += residual[o];
-      out[o] = v;
+    for (int reg = 0; reg < 16; reg++) orow[reg] = __shfl(rowid[m], (reg & 3) + 8 * (reg >> 2) + 4 * h, 64);
+    if (residual) {
+      // all residual reads first (a padded row reads row 0 and is dropped), then the adds: no load waits for another
+      float res[16][NT];
+#pragma unroll
+      for (int reg = 0; reg < 16; reg++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+          res[reg][nt] = residual[(size_t)(orow[reg] < 0 ? 0 : orow[reg]) * COUT + colbase + nt * 32 + r];
+#pragma unroll
+      for (int reg = 0; reg < 16; reg++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) acc[m][nt][reg] += res[reg][nt];
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+      if (orow[reg] < 0) continue;
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) out[(size_t)orow[reg] * COUT + colbase + nt * 32 + r] = acc[m][nt][reg];
     }
   }
 }
@@ -283,15 +345,31 @@ __global__ __launch_bounds__(256) void k_conv_reduce(const float *__restrict__ p
 
 static constexpr int kSplitTargetWaves = 2048;  // below this many waves the launch is offset-split
 
+template <int CT, int NCT, int COUT, int NT, int BPW, int MT>
+static void launch_k(const Plan &p, const float *in, int cin, const float *wp, const float *residual, float *out,
+                     hipStream_t s, int n_split, float *partial, BnPre pre) {
+  constexpr int WPBLK = COUT / 32 / NT;
+  constexpr int threads = BPW * WPBLK * 64;
+  const int groups = (p.n_blk + MT - 1) / MT;
+  dim3 grid((groups + BPW - 1) / BPW, n_split);
+  if (cin == CT * NCT)
+    hipLaunchKernelGGL((k_conv<CT, NCT, COUT, NT, BPW, MT, true>), grid, dim3(threads), 0, s, in, cin, wp, p.nbrT,
+                       p.n_blk * 32, p.rows, p.blkmask, p.n_blk, residual, out, n_split, partial, pre);
+  else
+    hipLaunchKernelGGL((k_conv<CT, NCT, COUT, NT, BPW, MT, false>), grid, dim3(threads), 0, s, in, cin, wp, p.nbrT,
+                       p.n_blk * 32, p.rows, p.blkmask, p.n_blk, residual, out, n_split, partial, pre);
+}
+
+// (The kernel's MT > 1 row groups -- one weight fetch for 64 rows -- measured slower on the MI355X than MT = 1:
+//  the per-block skip branches break the MFMA/LDS software pipeline and occupancy halves; not instantiated.)
 template <int CT, int NCT, int COUT, int NT, int BPW>
 static int launch_t(d3d_meta *m, const Plan &p, const float *in, int cin, const float *wp,
                     const float *residual, float *out, hipStream_t s, BnPre pre) {
   constexpr int WPBLK = COUT / 32 / NT;
-  constexpr int threads = BPW * WPBLK * 64;
   const int npos = p.n_blk * 32;
+  const long waves = (long)p.n_blk * WPBLK;
   int n_split = 1;
   if (BPW == 1 && p.K > 1 && m) {
-    const long waves = (long)p.n_blk * WPBLK;
     if (waves < kSplitTargetWaves) n_split = (int)std::min<long>(p.K, (kSplitTargetWaves + waves - 1) / waves);
   }
   float *partial = nullptr;
@@ -301,9 +379,7 @@ static int launch_t(d3d_meta *m, const Plan &p, const float *in, int cin, const 
     partial = m->arena.get<float>((size_t)n_split * npos * COUT);
     if (!partial) n_split = 1;  // arena full: fall back to the unsplit launch
   }
-  dim3 grid((p.n_blk + BPW - 1) / BPW, n_split);
-  hipLaunchKernelGGL((k_conv<CT, NCT, COUT, NT, BPW>), grid, dim3(threads), 0, s, in, cin, wp, p.nbrT, npos,
-                     p.rows, p.blkmask, p.n_blk, residual, out, n_split, partial, pre);
+  launch_k<CT, NCT, COUT, NT, BPW, 1>(p, in, cin, wp, residual, out, s, n_split, partial, pre);
   if (n_split > 1) {
     const long total = (long)npos * (COUT / 4);
     hipLaunchKernelGGL(k_conv_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, partial, n_split,
