@@ -382,6 +382,94 @@ __global__ __launch_bounds__(256) void k_plan_finish(const int32_t *__restrict__
   if (threadIdx.x < np / 32) blkmask[p0 / 32 + threadIdx.x] = bm[threadIdx.x];
 }
 
+// The whole finalisation of a SMALL plan (<= kSmallMax rows) in one single-workgroup launch: row masks, the
+// grouping sort, rows[] / nbrT / blkmask.  A dozen launches of 3-6 us each (mask, key, 7 radix-sort kernels,
+// finish) cost more in launch latency than this kernel's work; small layers are half of a network's plans.
+// Sort: stable LSD radix, 4 passes of 4 bits on a 16-bit key in LDS; thread t owns a contiguous chunk of rows and
+// the counter column cnt[digit][t], so ranks need no atomics and the order is deterministic.
+// key16 = (K - popcount) << 11 | (mask if K <= 11 else an 11-bit hash of it): heaviest rows first, equal masks
+// adjacent (hash collisions only cost a little padding).
+static constexpr int kSmallMax = 8192;
+static constexpr int kSmallThreads = 1024;
+__global__ __launch_bounds__(kSmallThreads) void k_plan_small(const int32_t *__restrict__ nbr,
+                                                              const uint32_t *__restrict__ mask_in, int n_rows, int npos,
+                                                              int K, int32_t *__restrict__ rows,
+                                                              int32_t *__restrict__ nbrT, uint32_t *__restrict__ blkmask) {
+  __shared__ uint32_t buf[2][kSmallMax];          // (key16 << 16) | row
+  __shared__ uint16_t cnt[16 * kSmallThreads];    // [digit][thread]
+  __shared__ uint32_t wsum[kSmallThreads / 64];
+  __shared__ uint32_t bm[kSmallMax / 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (n_rows + kSmallThreads - 1) / kSmallThreads;
+  const int i0 = min(n_rows, tid * per), i1 = min(n_rows, i0 + per);
+  for (int i = i0; i < i1; i++) {
+    uint32_t m;
+    if (mask_in)
+      m = mask_in[i];
+    else {
+      m = 0;
+      for (int k = 0; k < K; k++) m |= (nbr[(size_t)i * K + k] >= 0 ? 1u : 0u) << k;
+    }
+    const uint32_t lo = K <= 11 ? m : (m * 0x9E3779B1u) >> 21;
+    buf[0][i] = ((((uint32_t)(K - __popc(m)) << 11) | lo) << 16) | (uint32_t)i;
+  }
+  for (int b = tid; b < kSmallMax / 32; b += kSmallThreads) bm[b] = 0;
+  __syncthreads();
+  for (int pass = 0; pass < 4; pass++) {
+    const uint32_t *src = buf[pass & 1];
+    uint32_t *dst = buf[(pass & 1) ^ 1];
+    const int shift = 16 + 4 * pass;
+#pragma unroll
+    for (int d = 0; d < 16; d++) cnt[d * kSmallThreads + tid] = 0;
+    for (int i = i0; i < i1; i++) cnt[((src[i] >> shift) & 15u) * kSmallThreads + tid]++;
+    __syncthreads();
+    // exclusive scan of the flattened [digit][thread] counters: thread t owns entries [16 t, 16 t + 16)
+    uint32_t loc[16], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      loc[j] = sum;
+      sum += cnt[tid * 16 + j];
+    }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t base = inc - sum;
+    for (int w = 0; w < wave; w++) base += wsum[w];
+#pragma unroll
+    for (int j = 0; j < 16; j++) cnt[tid * 16 + j] = (uint16_t)(base + loc[j]);
+    __syncthreads();
+    for (int i = i0; i < i1; i++) {
+      const uint32_t v = src[i];
+      dst[cnt[((v >> shift) & 15u) * kSmallThreads + tid]++] = v;
+    }
+    __syncthreads();
+  }
+  const uint32_t *ord = buf[0];  // 4 passes: back in buffer 0
+  for (int p = tid; p < npos; p += kSmallThreads) rows[p] = p < n_rows ? (int32_t)(ord[p] & 0xffffu) : -1;
+  // nbrT[k][p] and the block masks: a wave takes (offset, 64 positions) items
+  const int nch = (npos + 63) / 64;
+  for (int item = wave; item < K * nch; item += kSmallThreads / 64) {
+    const int k = item / nch, p = (item - k * nch) * 64 + lane;
+    int v = -1;
+    if (p < npos) {
+      if (p < n_rows) v = nbr[(size_t)(ord[p] & 0xffffu) * K + k];
+      nbrT[(size_t)k * npos + p] = v;
+    }
+    const unsigned long long bal = __ballot(v >= 0);
+    if (lane == 0) {
+      if (bal & 0xffffffffull) atomicOr(&bm[p >> 5], 1u << k);
+      if (bal >> 32) atomicOr(&bm[(p >> 5) + 1], 1u << k);
+    }
+  }
+  __syncthreads();
+  for (int b = tid; b < npos / 32; b += kSmallThreads) blkmask[b] = bm[b];
+}
+
 // `mask_in` (may be null): per-row offset masks already computed by the caller together with the
 // rule count in plan.n_rules_dev.  The rule count stays on the device until somebody asks for it.
 int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan, hipStream_t s,
@@ -400,6 +488,12 @@ int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan
   plan.blkmask = blkmask;
   plan.n_rules = n_rows == 0 ? 0 : -1;
   if (n_rows == 0) return D3D_OK;
+  if (n_rows <= kSmallMax) {
+    hipLaunchKernelGGL(k_plan_small, dim3(1), dim3(kSmallThreads), 0, s, nbr, mask_in, n_rows, npos, K, rows, nbrT,
+                       blkmask);
+    D3D_LAUNCH_CHECK();
+    return D3D_OK;
+  }
   size_t mark = A.used;
   uint32_t *mask = mask_in;
   if (!mask) {
