@@ -382,9 +382,9 @@ __global__ __launch_bounds__(256) void k_plan_finish(const int32_t *__restrict__
   if (threadIdx.x < np / 32) blkmask[p0 / 32 + threadIdx.x] = bm[threadIdx.x];
 }
 
-// The whole finalisation of a SMALL plan (<= kSmallMax rows) in one single-workgroup launch: row masks, the
-// grouping sort, rows[] / nbrT / blkmask.  A dozen launches of 3-6 us each (mask, key, 7 radix-sort kernels,
-// finish) cost more in launch latency than this kernel's work; small layers are half of a network's plans.
+// Row masks and the grouping sort of a SMALL plan (<= kSmallMax rows) in one single-workgroup launch (k_plan_finish
+// follows).  The ten launches of 3-6 us each it replaces (mask, key, 7 radix-sort kernels) cost more in launch
+// latency than the work; small layers are half of a network's plans.
 // Sort: stable LSD radix, 4 passes of 4 bits on a 16-bit key in LDS; thread t owns a contiguous chunk of rows and
 // the counter column cnt[digit][t], so ranks need no atomics and the order is deterministic.
 // key16 = (K - popcount) << 11 | (mask if K <= 11 else an 11-bit hash of it): heaviest rows first, equal masks
@@ -392,13 +392,11 @@ __global__ __launch_bounds__(256) void k_plan_finish(const int32_t *__restrict__
 static constexpr int kSmallMax = 8192;
 static constexpr int kSmallThreads = 1024;
 __global__ __launch_bounds__(kSmallThreads) void k_plan_small(const int32_t *__restrict__ nbr,
-                                                              const uint32_t *__restrict__ mask_in, int n_rows, int npos,
-                                                              int K, int32_t *__restrict__ rows,
-                                                              int32_t *__restrict__ nbrT, uint32_t *__restrict__ blkmask) {
+                                                              const uint32_t *__restrict__ mask_in, int n_rows,
+                                                              int K, int32_t *__restrict__ rows) {
   __shared__ uint32_t buf[2][kSmallMax];          // (key16 << 16) | row
   __shared__ uint16_t cnt[16 * kSmallThreads];    // [digit][thread]
   __shared__ uint32_t wsum[kSmallThreads / 64];
-  __shared__ uint32_t bm[kSmallMax / 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (n_rows + kSmallThreads - 1) / kSmallThreads;
   const int i0 = min(n_rows, tid * per), i1 = min(n_rows, i0 + per);
@@ -413,7 +411,6 @@ __global__ __launch_bounds__(kSmallThreads) void k_plan_small(const int32_t *__r
     const uint32_t lo = K <= 11 ? m : (m * 0x9E3779B1u) >> 21;
     buf[0][i] = ((((uint32_t)(K - __popc(m)) << 11) | lo) << 16) | (uint32_t)i;
   }
-  for (int b = tid; b < kSmallMax / 32; b += kSmallThreads) bm[b] = 0;
   __syncthreads();
   for (int pass = 0; pass < 4; pass++) {
     const uint32_t *src = buf[pass & 1];
@@ -450,24 +447,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_plan_small(const int32_t *__r
     __syncthreads();
   }
   const uint32_t *ord = buf[0];  // 4 passes: back in buffer 0
-  for (int p = tid; p < npos; p += kSmallThreads) rows[p] = p < n_rows ? (int32_t)(ord[p] & 0xffffu) : -1;
-  // nbrT[k][p] and the block masks: a wave takes (offset, 64 positions) items
-  const int nch = (npos + 63) / 64;
-  for (int item = wave; item < K * nch; item += kSmallThreads / 64) {
-    const int k = item / nch, p = (item - k * nch) * 64 + lane;
-    int v = -1;
-    if (p < npos) {
-      if (p < n_rows) v = nbr[(size_t)(ord[p] & 0xffffu) * K + k];
-      nbrT[(size_t)k * npos + p] = v;
-    }
-    const unsigned long long bal = __ballot(v >= 0);
-    if (lane == 0) {
-      if (bal & 0xffffffffull) atomicOr(&bm[p >> 5], 1u << k);
-      if (bal >> 32) atomicOr(&bm[(p >> 5) + 1], 1u << k);
-    }
-  }
-  __syncthreads();
-  for (int b = tid; b < npos / 32; b += kSmallThreads) blkmask[b] = bm[b];
+  for (int p = tid; p < n_rows; p += kSmallThreads) rows[p] = (int32_t)(ord[p] & 0xffffu);
 }
 
 // `mask_in` (may be null): per-row offset masks already computed by the caller together with the
@@ -489,8 +469,9 @@ int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan
   plan.n_rules = n_rows == 0 ? 0 : -1;
   if (n_rows == 0) return D3D_OK;
   if (n_rows <= kSmallMax) {
-    hipLaunchKernelGGL(k_plan_small, dim3(1), dim3(kSmallThreads), 0, s, nbr, mask_in, n_rows, npos, K, rows, nbrT,
-                       blkmask);
+    hipLaunchKernelGGL(k_plan_small, dim3(1), dim3(kSmallThreads), 0, s, nbr, mask_in, n_rows, K, rows);
+    hipLaunchKernelGGL(k_plan_finish, dim3((npos + kTP - 1) / kTP), dim3(256), (size_t)kTP * (K | 1) * sizeof(int32_t),
+                       s, nbr, rows, n_rows, npos, K, nbrT, blkmask);
     D3D_LAUNCH_CHECK();
     return D3D_OK;
   }
