@@ -206,7 +206,7 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
   // B fragments (packed weights) of one (offset, Cin tile) step; with PREB they are fetched one step
   // ahead as well, so that the L2 latency hides under the previous step's MFMAs (small Cin tiles only:
   // the register cost is NT * CT/8 float4)
-  constexpr bool PREB = (CT <= 64);
+  constexpr bool PREB = false;  // measured: the double-buffered prefetch costs 64 VGPRs = one wave of occupancy
   constexpr int NQ = CT / 8;
   f32x4 bcur[PREB ? NQ * NT : 1], bnext[PREB ? NQ * NT : 1];
   auto load_b = [&](f32x4 *dst, int k, int ct) {
@@ -234,6 +234,19 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
     k_idx = NCT > 1 ? k : next_k(k);
     if (k_idx >= 0 && k_idx != k) load_idx(k_idx);
   }
+  constexpr int QA = PREB ? 1 : (NQ < 4 ? NQ : 4);
+  static_assert(NQ % QA == 0, "ring depth must divide the q-iterations of a step");
+  f32x4 ring[QA][NT];
+  if constexpr (!PREB) {
+    if (k >= 0) {
+      const float *wk0 = wp + ((size_t)(k * (CP / 4)) * COUT + colbase) * 4;
+#pragma unroll
+      for (int q = 0; q < QA; q++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+          ring[q][nt] = *(const f32x4 *)(wk0 + ((size_t)(2 * q + h) * COUT + nt * 32 + r) * 4);
+    }
+  }
   while (k >= 0) {
     commit_gather();
     block_sync();
@@ -252,6 +265,10 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
     }
     // ---- (MT*32) x (NT*32) += A[MT*32 x CT] * W[k][CT x cols] ----
     const float *wk = wp + ((size_t)(k * (CP / 4) + ct * (CT / 4)) * COUT + colbase) * 4;
+    // without PREB the fragments come through a ring of QA q-iterations in flight that runs across step
+    // boundaries: the last QA refills of a step fetch the first fragments of the next one (L2 latency is a few
+    // MFMA groups long; the compiler alone keeps only ~1 load ahead)
+    const float *wk_next = nk >= 0 ? wp + ((size_t)(nk * (CP / 4) + nct * (CT / 4)) * COUT + colbase) * 4 : wk;
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
       f32x4 b[NT];
@@ -260,7 +277,14 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
         if constexpr (PREB)
           b[nt] = bcur[q * NT + nt];
         else
-          b[nt] = *(const f32x4 *)(wk + ((size_t)(2 * q + h) * COUT + nt * 32 + r) * 4);
+          b[nt] = ring[q % QA][nt];
+      }
+      if constexpr (!PREB) {
+        const float *src = (q + QA < NQ) ? wk : wk_next;
+        const int qq = (q + QA) % NQ;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+          ring[q % QA][nt] = *(const f32x4 *)(src + ((size_t)(2 * qq + h) * COUT + nt * 32 + r) * 4);
       }
 #pragma unroll
       for (int m = 0; m < MT; m++) {
@@ -273,6 +297,19 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
           acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[nt][2], acc[m][nt], 0, 0, 0);
           acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[nt][3], acc[m][nt], 0, 0, 0);
         }
+      }
+    }
+    if constexpr (!PREB && MT == 1) {
+      // order of the step's instruction stream: the gather / index / first ring loads up front, then per q-iteration
+      // one LDS read (A of the next iteration), the MFMA group, one weight load (ring refill QA iterations ahead)
+      __builtin_amdgcn_sched_group_barrier(0x020, 2 * NIT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, NT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT - 1, 0);
       }
     }
     block_sync();

@@ -52,6 +52,7 @@ class ConvProfiler(object):
 
     def __init__(self):
         self.learn = False
+        self.focus = None   # None: time every convolution; else the set of (kind, fv, cin, cout) keys to time
         self.scene_key = None
         self.macs = {}      # scene_key -> [macs of call 0, 1, ...]
         self._idx = 0
@@ -62,12 +63,20 @@ class ConvProfiler(object):
         if learn:
             self.macs[scene_key] = []
 
-    def begin(self):
+    def wants(self, kind, fv, cin, cout):
+        return self.learn or self.focus is None or (kind, fv, cin, cout) in self.focus
+
+    def begin(self, kind=None, fv=None, cin=None, cout=None):
+        if kind is not None and not self.wants(kind, fv, cin, cout):
+            return None
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
         return ev
 
     def end(self, start, kind, fv, cin, cout, rows_in, rows_out, macs):
+        if start is None:       # not a focused family: only keep the call index aligned
+            self._idx += 1
+            return
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
         if self.learn:
@@ -282,14 +291,26 @@ def SubmanifoldConvolution_updateOutput(spatial_size, filter_size, m, input_feat
     prof = PROFILER
     want = ctypes.byref(macs) if ((prof is not None and prof.learn) or COUNT_MACS) else None
     if prof is not None:   # keep the rulebook build and the rule-count read-back out of the timed launch
-        check(lib().d3d_subm_prepare(m._h, ints(size), ints(filt), stream_of(), None))
-        t0 = prof.begin()
+        if prof.wants("subm", fv, cin, cout):
+            check(lib().d3d_subm_prepare(m._h, ints(size), ints(filt), stream_of(), None))
+        t0 = prof.begin("subm", fv, cin, cout)
     check(lib().d3d_subm_conv_forward(m._h, ints(size), ints(filt), ptr(input_features), cin, ptr(packed),
                                       cout, ptr(residual), ptr(output_features), stream_of(), want,
                                       _bn_struct(bn)))
     if prof is not None:
         prof.end(t0, "subm", fv, cin, cout, n, n, macs.value)
     return macs.value
+
+
+def Convolution_prepare(input_size, output_size, filter_size, filter_stride, m):
+    """Builds (or finds) the strided rulebook and the output grid ahead of the convolution that uses it
+    (Metadata::getRuleBook, Metadata.cpp:485-510) -> number of output sites.  One host read-back per NEW grid:
+    calling this for the whole pyramid right after the input layer keeps those read-backs out of the feature pass."""
+    isz, osz, filt, st = _size3(input_size), _size3(output_size), _size3(filter_size), _size3(filter_stride)
+    n_out = ctypes.c_int(0)
+    check(lib().d3d_conv_prepare(m._h, ints(isz), ints(osz), ints(filt), ints(st), stream_of(),
+                                 ctypes.byref(n_out), None))
+    return n_out.value
 
 
 def Convolution_updateOutput(input_size, output_size, filter_size, filter_stride, m, input_features,
@@ -308,7 +329,7 @@ def Convolution_updateOutput(input_size, output_size, filter_size, filter_stride
     prof = PROFILER
     want = ctypes.byref(macs) if ((prof is not None and prof.learn) or COUNT_MACS) else None
     if prof is not None:
-        t0 = prof.begin()
+        t0 = prof.begin("conv", fv, cin, cout)
     check(lib().d3d_conv_forward(m._h, ints(isz), ints(osz), ints(filt), ints(st), ptr(input_features), cin,
                                  ptr(packed), cout, ptr(output_features), stream_of(), want, _bn_struct(bn)))
     if prof is not None:
@@ -331,7 +352,7 @@ def Deconvolution_updateOutput(input_size, output_size, filter_size, filter_stri
     want = ctypes.byref(macs) if ((prof is not None and prof.learn) or COUNT_MACS) else None
     if prof is not None:
         check(lib().d3d_deconv_prepare(m._h, ints(isz), ints(osz), ints(filt), ints(st), stream_of(), None))
-        t0 = prof.begin()
+        t0 = prof.begin("deconv", fv, cin, cout)
     check(lib().d3d_deconv_forward(m._h, ints(isz), ints(osz), ints(filt), ints(st), ptr(input_features),
                                    cin, ptr(packed), cout, ptr(residual), ptr(output_features), stream_of(),
                                    want, _bn_struct(bn)))

@@ -110,8 +110,21 @@ class FPN_Net(torch.nn.Module):
                 i += 1
         return net
 
+    def prepare_geometry(self, net):
+        """All strided grids / rulebooks of the pyramid, built before the first feature kernel: each new grid costs
+        one host read-back of its site count, and here the stream holds only small geometry kernels when that
+        happens, so the feature pass that follows is enqueued without a single synchronisation."""
+        size = net.spatial_size
+        for k in range(1, len(self.m_downs)):
+            filt = scn.toLongTensor(self.dimension, self.down_kernels[k - 1])
+            stride = scn.toLongTensor(self.dimension, self.down_strides[k - 1])
+            out = (size - filt) // stride + 1
+            scn.SCN.Convolution_prepare(size, out, filt, stride, net.metadata)
+            size = out
+
     def forward_fpn(self, net):
         n_scales = len(self.m_downs)
+        self.prepare_geometry(net)
         downs = []
         for m in self.m_downs:
             net = self._run_down(m, net)
