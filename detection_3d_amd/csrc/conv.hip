@@ -432,6 +432,7 @@ static int launch_c(d3d_meta *m, const Plan &p, const float *in, int cin, const 
                     const float *residual, float *out, hipStream_t s, BnPre pre) {
   switch (cout) {
     case 32: return launch_t<CT, NCT, 32, 1, 4>(m, p, in, cin, wp, residual, out, s, pre);    // 4 independent waves
+    // (NT = 2 -- half as many waves per row block, no or fewer barriers -- measured slower: occupancy drops to 2)
     case 64: return launch_t<CT, NCT, 64, 1, 1>(m, p, in, cin, wp, residual, out, s, pre);    // 2 waves / block
     case 128: return launch_t<CT, NCT, 128, 1, 1>(m, p, in, cin, wp, residual, out, s, pre);  // 4 waves / block
     case 256: return launch_t<CT, NCT, 256, 1, 1>(m, p, in, cin, wp, residual, out, s, pre);  // 8 waves / block
