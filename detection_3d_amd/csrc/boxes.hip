@@ -424,7 +424,7 @@ __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long *__re
                                                   int max_keep, int32_t *__restrict__ keep,
                                                   int32_t *__restrict__ n_keep) {
   const int lane = threadIdx.x, sb = blockIdx.x;
-  const int n = seg_count(g, sb);
+  const int n = __builtin_amdgcn_readfirstlane(seg_count(g, sb));  // wave-uniform: keep it (and all row pointers) in SGPRs
   mask += (size_t)sb * g.n_max * ncb;  // rows of ncb words; this segment uses the first ceil(n/64)
   keep += (size_t)sb * g.n_max;
   n_keep += sb;
@@ -432,13 +432,22 @@ __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long *__re
   const unsigned long long lt = (1ull << lane) - 1ull;
   unsigned long long removed = 0;  // word `lane`
   int cnt = 0;
-  // rows of chunk c, word `lane` (words left of the diagonal are never read again)
+  // rows of chunk c, word `lane`.  Unconditional loads from a wave-uniform row pointer + the lane's word offset
+  // (lanes past the row end re-read its last word, rows past the chunk end re-read its last row): neither is ever
+  // used -- words left of the diagonal / beyond ncw are not read again, kept has no bit for a missing row -- and
+  // the loads stay free of per-lane predication and 64-bit vector address arithmetic (the sweep is one wave:
+  // every instruction is on the critical path)
+  const unsigned int lane_off = (unsigned int)min(lane, max(ncb - 1, 0)) * 8u;  // byte offset of this lane's word
   auto load_rows = [&](int c, unsigned long long *w) {
+    if (c >= ncw) return;
     const int base = c * 64;
-    const bool mine = c < ncw && lane > c && lane < ncw;
     const int nrow = min(64, n - base);
+    const unsigned long long *rowp = mask + (size_t)base * ncb;
 #pragma unroll
-    for (int b = 0; b < 64; b++) w[b] = (mine && b < nrow) ? mask[(size_t)(base + b) * ncb + lane] : 0ull;
+    for (int b = 0; b < 64; b++) {
+      const char *rp = (const char *)(rowp + (size_t)min(b, nrow - 1) * ncb);  // wave-uniform (SGPR pair)
+      w[b] = *(const unsigned long long *)(rp + lane_off);
+    }
   };
   auto load_diag = [&](int c) -> unsigned long long {
     const int base = c * 64;
@@ -451,7 +460,10 @@ __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long *__re
     const int nrow = min(64, n - base);
     load_rows(c + 1, w_next);
     const unsigned long long diag_next = load_diag(c + 1);
-    unsigned long long alive = ~__shfl(removed, c, 64);
+    // word c of the removed set, read into SGPRs: alive / kept / cnt and with them the whole chain stay scalar
+    unsigned long long alive =
+        ~(((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(removed >> 32), c) << 32) |
+          (unsigned int)__builtin_amdgcn_readlane((int)removed, c));
     if (nrow < 64) alive &= (1ull << nrow) - 1ull;
     unsigned long long kept = 0;
     const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
