@@ -36,7 +36,11 @@ __global__ void k_pack_weight_t(const float *__restrict__ w, int fv, int cin, in
 
 static constexpr int kDwBlocksPerWg = 64;
 
-// One workgroup: offset k = blockIdx.y, a run of row blocks, a group of <= 16 output tiles (32x32)
+// One workgroup: offset k = blockIdx.y, a run of kDwBlocksPerWg row blocks, a group of <= 16 output tiles (32x32).
+// The blocks of the run that have offset k are found with one ballot; their operands (32 gathered input rows and
+// the 32 dOut rows) go through registers one block ahead and their row indices two blocks ahead, all loads
+// branch-free (an absent row reads row 0 and is zeroed on the way to LDS), so the gathers of the next block fly
+// under the MFMAs of the current one -- the same pipeline as the forward kernel.
 template <int CP, int COUT>
 __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ in, int cin,
                                                  const float *__restrict__ d_out,
@@ -47,49 +51,103 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ in, i
   constexpr int NTI = CP / 32, NTJ = COUT / 32, T = NTI * NTJ;
   constexpr int TPG = T < 16 ? T : 16;             // tiles per group (grid.z)
   constexpr int TPW = (TPG + 3) / 4;               // tiles per wave
+  constexpr int A4 = CP / 4, B4 = COUT / 4;        // float4 per row
+  constexpr int NA = (32 * A4 + 255) / 256, NB = (32 * B4 + 255) / 256;  // float4 per thread and block
+  static_assert(kDwBlocksPerWg == 64, "one ballot covers the run");
   __shared__ __attribute__((aligned(16))) float As[32 * CP];
   __shared__ __attribute__((aligned(16))) float Bs[32 * COUT];
   const int k = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = lane & 31, kk = lane >> 5;
+  const int b0 = blockIdx.x * kDwBlocksPerWg;
+  // blocks of this run that have a rule at offset k
+  const uint32_t mymask = (b0 + lane < n_blk) ? blkmask[b0 + lane] : 0u;
+  unsigned long long active = __ballot((mymask >> k) & 1u);
+  if (!active) return;
   f32x16 acc[TPW];
 #pragma unroll
   for (int t = 0; t < TPW; t++)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
-  const int b0 = blockIdx.x * kDwBlocksPerWg, b1 = min(n_blk, b0 + kDwBlocksPerWg);
-  const bool vec = (cin % 4) == 0;
-  bool any = false;
-  for (int b = b0; b < b1; b++) {
-    if (!((blkmask[b] >> k) & 1u)) continue;  // wave-uniform
-    any = true;
-    __syncthreads();
-    // gather the 32 input rows of (offset k, block b) and the 32 dOut rows
-    for (int e = threadIdx.x; e < 32 * (CP / 4); e += 256) {
-      const int row = e / (CP / 4), c4 = e % (CP / 4);
-      const int s = nbrT[(size_t)k * npos + b * 32 + row];
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (s >= 0) {
-        const float *p = in + (size_t)s * cin + c4 * 4;
-        if (vec && c4 * 4 + 3 < cin) {
-          v = *(const f32x4 *)p;
-        } else {
-          if (c4 * 4 + 0 < cin) v[0] = p[0];
-          if (c4 * 4 + 1 < cin) v[1] = p[1];
-          if (c4 * 4 + 2 < cin) v[2] = p[2];
-          if (c4 * 4 + 3 < cin) v[3] = p[3];
-        }
+  const bool vec = (cin == CP);
+
+  int ia[NA], ib[NB];           // row indices of the block whose operands are requested next
+  f32x4 sa[NA], sb[NB];         // operands in flight
+  uint32_t real_a = 0, real_b = 0;
+  auto load_idx = [&](int b) {
+#pragma unroll
+    for (int j = 0; j < NA; j++) {
+      const int e = threadIdx.x + j * 256;
+      ia[j] = nbrT[(size_t)k * npos + b * 32 + (e < 32 * A4 ? e / A4 : 0)];
+    }
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+      const int e = threadIdx.x + j * 256;
+      ib[j] = rows[b * 32 + (e < 32 * B4 ? e / B4 : 0)];
+    }
+  };
+  auto issue_data = [&]() {
+    real_a = real_b = 0;
+#pragma unroll
+    for (int j = 0; j < NA; j++) {
+      const int e = threadIdx.x + j * 256;
+      const int c4 = e % A4;
+      const int s = e < 32 * A4 ? ia[j] : -1;
+      if (s >= 0) real_a |= 1u << j;
+      const float *p = in + (size_t)(s < 0 ? 0 : s) * cin + c4 * 4;
+      if (vec) {
+        sa[j] = *(const f32x4 *)p;
+      } else {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c4 * 4 + 0 < cin) v[0] = p[0];
+        if (c4 * 4 + 1 < cin) v[1] = p[1];
+        if (c4 * 4 + 2 < cin) v[2] = p[2];
+        if (c4 * 4 + 3 < cin) v[3] = p[3];
+        sa[j] = v;
       }
-      *(f32x4 *)(As + row * CP + c4 * 4) = v;
     }
-    for (int e = threadIdx.x; e < 32 * (COUT / 4); e += 256) {
-      const int row = e / (COUT / 4), c4 = e % (COUT / 4);
-      const int o = rows[b * 32 + row];
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (o >= 0) v = *(const f32x4 *)(d_out + (size_t)o * COUT + c4 * 4);
-      *(f32x4 *)(Bs + row * COUT + c4 * 4) = v;
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+      const int e = threadIdx.x + j * 256;
+      const int c4 = e % B4;
+      const int o = e < 32 * B4 ? ib[j] : -1;
+      if (o >= 0) real_b |= 1u << j;
+      sb[j] = *(const f32x4 *)(d_out + (size_t)(o < 0 ? 0 : o) * COUT + c4 * 4);
     }
+  };
+  auto commit = [&]() {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NA; j++) {
+      const int e = threadIdx.x + j * 256;
+      if (e < 32 * A4) *(f32x4 *)(As + (e / A4) * CP + (e % A4) * 4) = ((real_a >> j) & 1u) ? sa[j] : zero;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+      const int e = threadIdx.x + j * 256;
+      if (e < 32 * B4) *(f32x4 *)(Bs + (e / B4) * COUT + (e % B4) * 4) = ((real_b >> j) & 1u) ? sb[j] : zero;
+    }
+  };
+  auto pop = [&]() -> int {  // next active block of the run, or -1
+    if (!active) return -1;
+    const int j = __builtin_ctzll(active);
+    active &= active - 1;
+    return b0 + j;
+  };
+
+  int bc = pop();               // block being computed
+  load_idx(bc);
+  issue_data();
+  int bn = pop();               // block whose operands are requested during bc's MFMAs
+  if (bn >= 0) load_idx(bn);
+  while (bc >= 0) {
+    commit();
     __syncthreads();
+    const int bnn = bn >= 0 ? pop() : -1;
+    if (bn >= 0) {
+      issue_data();               // operands of bn (its indices arrived during the previous block)
+      if (bnn >= 0) load_idx(bnn);
+    }
 #pragma unroll
     for (int t = 0; t < TPW; t++) {
       const int tile = blockIdx.z * TPG + wave * TPW + t;
@@ -102,8 +160,10 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ in, i
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[t], 0, 0, 0);
       }
     }
+    __syncthreads();
+    bc = bn;
+    bn = bnn;
   }
-  if (!any) return;
 #pragma unroll
   for (int t = 0; t < TPW; t++) {
     const int tile = blockIdx.z * TPG + wave * TPW + t;
