@@ -35,6 +35,7 @@ __global__ void k_pack_weight_t(const float *__restrict__ w, int fv, int cin, in
 }
 
 static constexpr int kDwBlocksPerWg = 64;
+static constexpr int kDwTargetWgs = 1024;
 
 // One workgroup: offset k = blockIdx.y, a run of kDwBlocksPerWg row blocks, a group of <= 16 output tiles (32x32).
 // The blocks of the run that have offset k are found with one ballot; their operands (32 gathered input rows and
@@ -46,22 +47,22 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ in, i
                                                  const float *__restrict__ d_out,
                                                  const int32_t *__restrict__ nbrT, int npos,
                                                  const int32_t *__restrict__ rows,
-                                                 const uint32_t *__restrict__ blkmask, int n_blk,
+                                                 const uint32_t *__restrict__ blkmask, int n_blk, int run,
                                                  float *__restrict__ dW) {
   constexpr int NTI = CP / 32, NTJ = COUT / 32, T = NTI * NTJ;
   constexpr int TPG = T < 16 ? T : 16;             // tiles per group (grid.z)
   constexpr int TPW = (TPG + 3) / 4;               // tiles per wave
   constexpr int A4 = CP / 4, B4 = COUT / 4;        // float4 per row
   constexpr int NA = (32 * A4 + 255) / 256, NB = (32 * B4 + 255) / 256;  // float4 per thread and block
-  static_assert(kDwBlocksPerWg == 64, "one ballot covers the run");
+  static_assert(kDwBlocksPerWg == 64, "one ballot covers the longest run");
   __shared__ __attribute__((aligned(16))) float As[32 * CP];
   __shared__ __attribute__((aligned(16))) float Bs[32 * COUT];
   const int k = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = lane & 31, kk = lane >> 5;
-  const int b0 = blockIdx.x * kDwBlocksPerWg;
-  // blocks of this run that have a rule at offset k
-  const uint32_t mymask = (b0 + lane < n_blk) ? blkmask[b0 + lane] : 0u;
+  const int b0 = blockIdx.x * run;
+  // blocks of this run (<= 64) that have a rule at offset k
+  const uint32_t mymask = (lane < run && b0 + lane < n_blk) ? blkmask[b0 + lane] : 0u;
   unsigned long long active = __ballot((mymask >> k) & 1u);
   if (!active) return;
   f32x16 acc[TPW];
@@ -182,9 +183,14 @@ template <int CP, int COUT>
 static int launch_dw_t(const Plan &p, const float *in, int cin, const float *d_out, float *dW, hipStream_t s) {
   constexpr int T = (CP / 32) * (COUT / 32);
   constexpr int TPG = T < 16 ? T : 16;
-  dim3 grid((p.n_blk + kDwBlocksPerWg - 1) / kDwBlocksPerWg, p.K, (T + TPG - 1) / TPG);
+  // run length: long runs amortise the final atomics of a workgroup (T * 1024 of them), short runs keep a small
+  // plan from being walked serially by a handful of workgroups -- aim at >= kDwTargetWgs workgroups
+  const int nz = (T + TPG - 1) / TPG;
+  long run = ((long)p.n_blk * p.K * nz + kDwTargetWgs - 1) / kDwTargetWgs;
+  run = std::max<long>(2, std::min<long>(kDwBlocksPerWg, run));
+  dim3 grid((unsigned)((p.n_blk + run - 1) / run), p.K, nz);
   hipLaunchKernelGGL((k_conv_dw<CP, COUT>), grid, dim3(256), 0, s, in, cin, d_out, p.nbrT, p.n_blk * 32, p.rows,
-                     p.blkmask, p.n_blk, dW);
+                     p.blkmask, p.n_blk, (int)run, dW);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }
