@@ -52,11 +52,11 @@ class ConvProfiler(object):
 
     def __init__(self):
         self.learn = False
-        self.focus = None   # None: time every convolution; else the set of (kind, fv, cin, cout) keys to time
+        self.focus = None   # None: time every convolution; else the set of (cin, cout) kernel keys to time
         self.scene_key = None
         self.macs = {}      # scene_key -> [macs of call 0, 1, ...]
         self._idx = 0
-        self.records = []   # (key, flops, compulsory_bytes, start_event, end_event)
+        self.records = []   # ((cin, cout) = one k_conv instantiation, flops, compulsory_bytes, start_event, end_event)
 
     def start_scene(self, scene_key, learn):
         self.scene_key, self.learn, self._idx = scene_key, learn, 0
@@ -64,7 +64,7 @@ class ConvProfiler(object):
             self.macs[scene_key] = []
 
     def wants(self, kind, fv, cin, cout):
-        return self.learn or self.focus is None or (kind, fv, cin, cout) in self.focus
+        return self.learn or self.focus is None or (cin, cout) in self.focus
 
     def begin(self, kind=None, fv=None, cin=None, cout=None):
         if kind is not None and not self.wants(kind, fv, cin, cout):
@@ -86,7 +86,7 @@ class ConvProfiler(object):
         self._idx += 1
         rules = macs / max(cin * cout, 1)
         # FLOPs = 2*rules*Cin*Cout; compulsory bytes = 4*(rows_in*Cin + rows_out*Cout) + 8*rules
-        self.records.append(((kind, fv, cin, cout), 2.0 * macs, 4.0 * (rows_in * cin + rows_out * cout) + 8.0 * rules,
+        self.records.append(((cin, cout), 2.0 * macs, 4.0 * (rows_in * cin + rows_out * cout) + 8.0 * rules,
                              start, ev))
 
     def summary(self):
