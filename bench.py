@@ -41,6 +41,29 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(template):
+    """HBM-side bytes per launch of `template` from the committed PMC passes (profiles/r01_pmc_{fetch,write}.csv:
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` of this script, summed per kernel name, in KB).
+    gfx950 correction of MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts wide coalesced reads at half their bytes.
+    None when the files are absent."""
+    import csv
+    tot = 0.0
+    for name, factor in (("r01_pmc_fetch.csv", 2.0), ("r01_pmc_write.csv", 1.0)):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            return None
+        hit = None
+        with open(path) as f:
+            for row in csv.reader(f):
+                if row and template in row[0]:
+                    hit = float(row[3]) * 1024.0 * factor
+                    break
+        if hit is None:
+            return None
+        tot += hit
+    return tot
+
+
 def kernel_name(key):
     """(Cin, Cout) -> the k_conv instantiation launch_conv picks (detection_3d_amd/csrc/conv.hip), as rocprofv3 prints it"""
     cin, cout = key
@@ -158,7 +181,9 @@ def main():
         tflops = d["flops"] / d["calls"] / (per_launch_ms * 1e-3) / 1e12
         gbs = d["bytes"] / d["calls"] / (per_launch_ms * 1e-3) / 1e9
         roof = {"bound": "mfma", "achieved": round(tflops, 3), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tflops / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(tflops / FP32_MATRIX_PEAK_TFLOPS, 4),
+                "traffic": pmc_traffic(kernel_name(key).split(" (")[0].replace("d3d::", "")),
+                "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE of profiles/r01_pmc_*.csv)",
                 "kernel": kernel_name(key),
                 "launches_per_step": d["calls"] / args.steps, "avg_launch_us": round(per_launch_ms * 1e3, 1),
                 "algorithmic_gflop_per_launch": round(d["flops"] / d["calls"] / 1e9, 3),
