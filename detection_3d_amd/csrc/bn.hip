@@ -181,7 +181,8 @@ __global__ void k_bn_eval_stats(const float *running_mean, const float *running_
   save_invstd[c] = powf(running_var[c] + eps, -0.5f);  // BatchNormalization.cpp:40-44
 }
 
-// y = leaky(x * w + b), w = invstd*gamma, b = -mean*w + beta (BatchNormalization.cpp:46-59)
+// y = leaky(fma(x, w, b)), w = invstd*gamma, b = -mean*w + beta (BatchNormalization.cpp:46-59); leakiness 0 is
+// max(t, 0): the sign of a zero and NaN -> 0 differ from t * 0, nothing else
 __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, float *__restrict__ y,
                                                   size_t total, int C,
                                                   const float *__restrict__ save_mean,
@@ -192,23 +193,22 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, f
   if (i >= total) return;
   if ((C & 3) == 0) {
     const int c = (int)(i % C);
-    float4 v = *(const float4 *)(x + i);
-    float o[4] = {v.x, v.y, v.z, v.w};
+    const d3d_f32x4 v = *(const d3d_f32x4 *)(x + i);
+    d3d_f32x4 w, b;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      float w = save_invstd[c + j] * (weight ? weight[c + j] : 1.f);
-      float b = -save_mean[c + j] * w + (bias ? bias[c + j] : 0.f);
-      float t = o[j] * w + b;
-      o[j] = t * ((t > 0) ? 1.f : leakiness);
+      w[j] = save_invstd[c + j] * (weight ? weight[c + j] : 1.f);
+      b[j] = -save_mean[c + j] * w[j] + (bias ? bias[c + j] : 0.f);
     }
-    *(float4 *)(y + i) = make_float4(o[0], o[1], o[2], o[3]);
+    *(d3d_f32x4 *)(y + i) = bn_act(v, w, b, leakiness);   // the same expression as the convolutions' fused prologue
   } else {
     for (size_t k = i; k < i + 4 && k < total; k++) {
       const int c = (int)(k % C);
       float w = save_invstd[c] * (weight ? weight[c] : 1.f);
       float b = -save_mean[c] * w + (bias ? bias[c] : 0.f);
-      float t = x[k] * w + b;
-      y[k] = t * ((t > 0) ? 1.f : leakiness);
+      const d3d_f32x4 t = bn_act(d3d_f32x4{x[k], 0.f, 0.f, 0.f}, d3d_f32x4{w, 0.f, 0.f, 0.f}, d3d_f32x4{b, 0.f, 0.f, 0.f},
+                                 leakiness);
+      y[k] = t[0];
     }
   }
 }

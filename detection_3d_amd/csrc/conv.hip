@@ -101,7 +101,8 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
   uint32_t mask = 0;
 #pragma unroll
   for (int m = 0; m < MT; m++) {
-    sub[m] = blk0 + m < n_blk ? blkmask[blk0 + m] : 0u;
+    // wave-uniform: keep it (and with it k, the weight / index base pointers and the loop control) in SGPRs
+    sub[m] = __builtin_amdgcn_readfirstlane(blk0 + m < n_blk ? blkmask[blk0 + m] : 0u);
     mask |= sub[m];
   }
   if (n_split > 1) {
@@ -151,38 +152,63 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
       bnb[t] = -mu * bnw[t] + be;
     }
   }
-  uint32_t stage_real = 0;  // bit it: stage[it] holds a real row
+  // The fp32 MFMA shares the SIMD's vector ALU with ordinary VALU instructions (scripts/mfma_probe.hip: every VALU
+  // instruction issued by ANY wave of the SIMD takes ~3.5 cycles away from the matrix pipe, nothing co-executes),
+  // so the gather is written to cost as few VALU instructions as possible: wave-uniform (scalar) base pointers +
+  // 32-bit per-lane byte offsets, one multiplier per row (1 = real, 0 = absent neighbour) instead of per-element
+  // selects, fused multiply-add + max for the BatchNorm + ReLU prologue.
+  uint32_t stage_real = 0;  // (generic path) bit it: stage[it] holds a real row
+  float mreal[NIT];         // (fast path) 1.f for a real row, 0.f for an absent one
   int stage_ct = 0;
-  uint32_t idx_on = 0;  // bit it: idx[it] is a real plan entry (the loaded value is not touched before use)
+  uint32_t idx_on = 0;  // (generic path) bit it: idx[it] is a real plan entry
+  constexpr bool FAST = VEC && MT == 1 && (32 % RPP == 0);
+  const uint32_t lane_piece = (uint32_t)gc4 * 16u, lane_idx = (uint32_t)grow * 4u;
   auto load_idx = [&](int k) {
-    idx_on = 0;
+    if constexpr (FAST) {
+      const char *kb = (const char *)(nb + (size_t)k * npos);  // wave-uniform
 #pragma unroll
-    for (int it = 0; it < NIT; it++) {
-      const int row = it * RPP + grow;
-      const int mb = (32 % RPP == 0) ? (it * RPP) / 32 : (row >> 5);  // compile-time when a pass stays in one block
-      const bool on = row < GR && p0 + row < npos && ((sub[mb < MT ? mb : 0] >> k) & 1u);
-      idx[it] = nb[(size_t)k * npos + (on ? row : 0)];
-      idx_on |= (on ? 1u : 0u) << it;
+      for (int it = 0; it < NIT; it++) idx[it] = *(const int32_t *)(kb + (lane_idx + (uint32_t)(it * RPP * 4)));
+    } else {
+      idx_on = 0;
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int row = it * RPP + grow;
+        const int mb = (32 % RPP == 0) ? (it * RPP) / 32 : (row >> 5);  // compile-time when a pass stays in one block
+        const bool on = row < GR && p0 + row < npos && ((sub[mb < MT ? mb : 0] >> k) & 1u);
+        idx[it] = nb[(size_t)k * npos + (on ? row : 0)];
+        idx_on |= (on ? 1u : 0u) << it;
+      }
     }
   };
   auto issue_data = [&](int ct) {
-    stage_real = 0;
     stage_ct = ct;
+    if constexpr (FAST) {
+      const char *base = (const char *)(in + ct * CT);  // wave-uniform; rows are CP * 4 bytes (< 4 GiB tensor)
 #pragma unroll
-    for (int it = 0; it < NIT; it++) {
-      const int s = ((idx_on >> it) & 1u) ? idx[it] : -1;
-      const float *p = in + (size_t)(s < 0 ? 0 : s) * cin + ct * CT + gc4 * 4;
-      if (s >= 0) stage_real |= 1u << it;
-      if constexpr (VEC) {
-        stage[it] = *(const f32x4 *)p;
-      } else {
-        const int c = ct * CT + gc4 * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (c + 0 < cin) v[0] = p[0];
-        if (c + 1 < cin) v[1] = p[1];
-        if (c + 2 < cin) v[2] = p[2];
-        if (c + 3 < cin) v[3] = p[3];
-        stage[it] = v;
+      for (int it = 0; it < NIT; it++) {
+        const int s = idx[it];
+        mreal[it] = s >= 0 ? 1.f : 0.f;
+        const uint32_t off = (uint32_t)(s < 0 ? 0 : s) * (uint32_t)(CP * 4) + lane_piece;
+        stage[it] = *(const f32x4 *)(base + off);
+      }
+    } else {
+      stage_real = 0;
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int s = ((idx_on >> it) & 1u) ? idx[it] : -1;
+        const float *p = in + (size_t)(s < 0 ? 0 : s) * cin + ct * CT + gc4 * 4;
+        if (s >= 0) stage_real |= 1u << it;
+        if constexpr (VEC) {
+          stage[it] = *(const f32x4 *)p;
+        } else {
+          const int c = ct * CT + gc4 * 4;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (c + 0 < cin) v[0] = p[0];
+          if (c + 1 < cin) v[1] = p[1];
+          if (c + 2 < cin) v[2] = p[2];
+          if (c + 3 < cin) v[3] = p[3];
+          stage[it] = v;
+        }
       }
     }
   };
@@ -193,12 +219,11 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
     for (int it = 0; it < NIT; it++) {
       const int row = it * RPP + grow;
       f32x4 v = stage[it];
-      if (pre.mean) {
-        v = v * bw + bb;
-#pragma unroll
-        for (int j = 0; j < 4; j++) v[j] = v[j] * ((v[j] > 0) ? 1.f : pre.leak);
-      }
-      v = ((stage_real >> it) & 1u) ? v : zero;
+      if (pre.mean) v = bn_act(v, bw, bb, pre.leak);
+      if constexpr (FAST)
+        v = v * mreal[it];
+      else
+        v = ((stage_real >> it) & 1u) ? v : zero;
       if (row < GR) *(f32x4 *)(As + row * LDA + gc4 * 4) = v;
     }
   };
@@ -237,14 +262,15 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
   constexpr int QA = PREB ? 1 : (NQ < 4 ? NQ : 4);
   static_assert(NQ % QA == 0, "ring depth must divide the q-iterations of a step");
   f32x4 ring[QA][NT];
+  const uint32_t lane_b = (uint32_t)(h * COUT + r) * 16u;   // this lane's byte offset inside a weight fragment row
   if constexpr (!PREB) {
     if (k >= 0) {
-      const float *wk0 = wp + ((size_t)(k * (CP / 4)) * COUT + colbase) * 4;
+      const char *wk0 = (const char *)(wp + ((size_t)(k * (CP / 4)) * COUT + colbase) * 4);
 #pragma unroll
       for (int q = 0; q < QA; q++)
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
-          ring[q][nt] = *(const f32x4 *)(wk0 + ((size_t)(2 * q + h) * COUT + nt * 32 + r) * 4);
+          ring[q][nt] = *(const f32x4 *)(wk0 + (lane_b + (uint32_t)((2 * q * COUT + nt * 32) * 16)));
     }
   }
   while (k >= 0) {
@@ -280,11 +306,11 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
           b[nt] = ring[q % QA][nt];
       }
       if constexpr (!PREB) {
-        const float *src = (q + QA < NQ) ? wk : wk_next;
+        const char *src = (const char *)((q + QA < NQ) ? wk : wk_next);   // wave-uniform base + per-lane byte offset
         const int qq = (q + QA) % NQ;
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
-          ring[q % QA][nt] = *(const f32x4 *)(src + ((size_t)(2 * qq + h) * COUT + nt * 32 + r) * 4);
+          ring[q % QA][nt] = *(const f32x4 *)(src + (lane_b + (uint32_t)((2 * qq * COUT + nt * 32) * 16)));
       }
 #pragma unroll
       for (int m = 0; m < MT; m++) {
@@ -445,6 +471,8 @@ int launch_conv(d3d_meta *m, const Plan &p, const float *in, int cin, const floa
                 const float *residual, float *out, hipStream_t s, const d3d_bn_prologue *bn) {
   if (p.n_rows == 0) return D3D_OK;
   D3D_REQUIRE(in && packed_w && out, "convolution: null pointer");
+  D3D_REQUIRE((size_t)p.n_in * (size_t)cin * 4 < ((size_t)1 << 32),
+              "convolution: gathered tensor of %d rows x %d channels exceeds the 4 GiB of the 32-bit gather offsets", p.n_in, cin);
   BnPre pre = {nullptr, nullptr, nullptr, nullptr, 0.f};
   if (bn && bn->mean) {
     D3D_REQUIRE(bn->invstd && cin % 8 == 0 && padded_cin(cin) == cin, "fused BatchNorm prologue needs Cin in {32,64,128,256}");

@@ -558,6 +558,8 @@ int get_deconv_plan(d3d_meta *m, const int *fine_size, const int *filt, const in
     int K = filt[0] * filt[1] * filt[2];
     int rc = finalize_plan(m, raw->second.nbr_dec, raw->second.n_in, K, p, s, nullptr);
     if (rc) return rc;
+    auto go = m->grids.find(raw->second.out_size);
+    p.n_in = go == m->grids.end() ? 0 : go->second.n;   // gathers from the coarse tensor
     it = m->plans.emplace(key, p).first;
   }
   *out = &it->second;
@@ -966,6 +968,7 @@ int d3d_subm_prepare(d3d_meta *m, const int *size, const int *filt, void *stream
       }
       if (rc) return rc;
     }
+    p.n_in = g->n;
     it = m->plans.emplace(key, p).first;
   }
   if (n_rules_host) return plan_rules(m, it->second, s, n_rules_host);
@@ -1058,6 +1061,7 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
     raw.n_in = n_in;
     raw.out_size = Size3{out_size[0], out_size[1], out_size[2]};
     m->strided_raw[key] = raw;
+    p.n_in = n_in;
     it = m->plans.emplace(key, p).first;
   }
   if (n_out_host) *n_out_host = it->second.n_rows;
