@@ -364,27 +364,31 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
   }
 #pragma unroll
   for (int m = 0; m < MT; m++) {
-    int orow[16];
+    // four rows at a time: residual reads first (a padded row reads row 0 and is dropped), then adds and stores --
+    // no load waits for another, and the epilogue does not set the kernel's register budget
 #pragma unroll
-    for (int reg = 0; reg < 16; reg++) orow[reg] = __shfl(rowid[m], (reg & 3) + 8 * (reg >> 2) + 4 * h, 64);
-    if (residual) {
-      // all residual reads first (a padded row reads row 0 and is dropped), then the adds: no load waits for another
-      float res[16][NT];
+    for (int g4 = 0; g4 < 4; g4++) {
+      int orow[4];
+      float res[4][NT];
 #pragma unroll
-      for (int reg = 0; reg < 16; reg++)
+      for (int j = 0; j < 4; j++) orow[j] = __shfl(rowid[m], j + 8 * g4 + 4 * h, 64);
+      if (residual) {
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++)
-          res[reg][nt] = residual[(size_t)(orow[reg] < 0 ? 0 : orow[reg]) * COUT + colbase + nt * 32 + r];
+        for (int j = 0; j < 4; j++)
 #pragma unroll
-      for (int reg = 0; reg < 16; reg++)
+          for (int nt = 0; nt < NT; nt++)
+            res[j][nt] = residual[(size_t)(orow[j] < 0 ? 0 : orow[j]) * COUT + colbase + nt * 32 + r];
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++) acc[m][nt][reg] += res[reg][nt];
-    }
+        for (int j = 0; j < 4; j++)
 #pragma unroll
-    for (int reg = 0; reg < 16; reg++) {
-      if (orow[reg] < 0) continue;
+          for (int nt = 0; nt < NT; nt++) acc[m][nt][g4 * 4 + j] += res[j][nt];
+      }
 #pragma unroll
-      for (int nt = 0; nt < NT; nt++) out[(size_t)orow[reg] * COUT + colbase + nt * 32 + r] = acc[m][nt][reg];
+      for (int j = 0; j < 4; j++) {
+        if (orow[j] < 0) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) out[(size_t)orow[j] * COUT + colbase + nt * 32 + r] = acc[m][nt][g4 * 4 + j];
+      }
     }
   }
 }
