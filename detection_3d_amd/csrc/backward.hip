@@ -254,6 +254,87 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial(const float *__restrict_
     __syncthreads();
   }
 }
+// Same sums with 16-byte loads: threads = float4 channel groups x concurrent rows (1024 per workgroup), butterfly
+// inside the wave, one LDS entry per wave -- the layout of k_bn_stats (bn.hip).  planes % 4 == 0, planes/4 | 1024.
+__global__ __launch_bounds__(1024) void k_bn_bwd_partial4(const float *__restrict__ x, const float *__restrict__ y,
+                                                          const float *__restrict__ dy, int rows, int C,
+                                                          const float *__restrict__ mean, float leak,
+                                                          double *__restrict__ partial) {
+  __shared__ double red[4][1024];
+  const int tid = threadIdx.x;
+  const int C4 = C >> 2;
+  const int LPR = C4 < 1024 ? C4 : 1024;
+  const int RL = 1024 / LPR;
+  const int rl = tid / LPR, cl = tid - rl * LPR;
+  const int per = (rows + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
+  for (int g4 = cl; g4 < C4; g4 += LPR) {
+    const f32x4 mu = *(const f32x4 *)(mean + g4 * 4);
+    double s[4] = {0, 0, 0, 0}, dp[4] = {0, 0, 0, 0};
+    for (int r = r0 + rl; r < r1; r += RL) {
+      const size_t i = (size_t)r * C + g4 * 4;
+      const f32x4 vx = *(const f32x4 *)(x + i), vy = *(const f32x4 *)(y + i), vd = *(const f32x4 *)(dy + i);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float d = vd[j] * ((vy[j] > 0) ? 1.f : leak);
+        s[j] += (double)d;
+        dp[j] += (double)((vx[j] - mu[j]) * d);
+      }
+    }
+    if (LPR < 64)
+      for (int d = LPR; d < 64; d <<= 1)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          s[j] += __shfl_xor(s[j], d, 64);
+          dp[j] += __shfl_xor(dp[j], d, 64);
+        }
+    const int NE = LPR < 64 ? 16 : RL;
+    const int e = LPR < 64 ? (tid >> 6) : rl;
+    const bool holder = LPR < 64 ? (tid & 63) < LPR : true;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      double *vals = half ? dp : s;
+      if (holder)
+#pragma unroll
+        for (int j = 0; j < 4; j++) red[j][e * LPR + cl] = vals[j];
+      __syncthreads();
+      if (e == 0 && holder)
+        for (int q = 1; q < NE; q++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) vals[j] += red[j][q * LPR + cl];
+      __syncthreads();
+    }
+    if (e == 0 && holder) {
+      double *pp = partial + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        pp[g4 * 4 + j] = s[j];
+        pp[C + g4 * 4 + j] = dp[j];
+      }
+    }
+  }
+}
+// dx for 4 channels per thread
+__global__ __launch_bounds__(256) void k_bn_bwd_apply4(const float *__restrict__ x, const float *__restrict__ y,
+                                                       const float *__restrict__ dy, float *__restrict__ dx,
+                                                       size_t total4, int C, const float *__restrict__ mean,
+                                                       const float *__restrict__ invstd,
+                                                       const float *__restrict__ weight,
+                                                       const float *__restrict__ grad_mean,
+                                                       const float *__restrict__ kcoef, float leak) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total4) return;
+  const size_t i = t * 4;
+  const int c = (int)(i % C);
+  const f32x4 vx = *(const f32x4 *)(x + i), vy = *(const f32x4 *)(y + i), vd = *(const f32x4 *)(dy + i);
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const float d = vd[j] * ((vy[j] > 0) ? 1.f : leak);
+    o[j] = (d - grad_mean[c + j] - (vx[j] - mean[c + j]) * kcoef[c + j]) * invstd[c + j] * (weight ? weight[c + j] : 1.f);
+  }
+  *(f32x4 *)(dx + i) = o;
+}
 __global__ __launch_bounds__(256) void k_bn_bwd_finish(const double *__restrict__ partial, int nblk, int rows,
                                                        int C, const float *__restrict__ invstd,
                                                        float *grad_mean, float *kcoef, float *d_weight,
@@ -407,13 +488,25 @@ int d3d_bn_backward(const float *in, const float *out, const float *d_out, float
   double *partial = (double *)scratch;
   float *grad_mean = (float *)((char *)scratch + (size_t)kBnBwdBlocks * 2 * planes * sizeof(double));
   float *kcoef = grad_mean + planes;
-  hipLaunchKernelGGL(k_bn_bwd_partial, dim3(nblk), dim3(256), 256 * 2 * sizeof(double), s, in, out, d_out, rows, planes,
-                     save_mean, leakiness, partial);
+  const bool vec4 = planes % 4 == 0 && 1024 % (planes / 4) == 0 && (((uintptr_t)in | (uintptr_t)out | (uintptr_t)d_out | (uintptr_t)d_in) & 15) == 0;
+  if (vec4) {
+    const int RL = 1024 / (planes / 4);
+    nblk = std::max(1, std::min(kBnBwdBlocks, (rows + 8 * RL - 1) / (8 * RL)));
+    hipLaunchKernelGGL(k_bn_bwd_partial4, dim3(nblk), dim3(1024), 0, s, in, out, d_out, rows, planes, save_mean, leakiness,
+                       partial);
+  } else {
+    hipLaunchKernelGGL(k_bn_bwd_partial, dim3(nblk), dim3(256), 256 * 2 * sizeof(double), s, in, out, d_out, rows, planes,
+                       save_mean, leakiness, partial);
+  }
   hipLaunchKernelGGL(k_bn_bwd_finish, dim3((planes + 31) / 32), dim3(256), 0, s, partial, nblk, rows, planes,
                      save_invstd, grad_mean, kcoef, d_weight, d_bias);
   size_t total = (size_t)rows * planes;
-  hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, d_out, d_in, total,
-                     planes, save_mean, save_invstd, weight, grad_mean, kcoef, leakiness);
+  if (vec4)
+    hipLaunchKernelGGL(k_bn_bwd_apply4, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, in, out, d_out, d_in,
+                       total / 4, planes, save_mean, save_invstd, weight, grad_mean, kcoef, leakiness);
+  else
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, d_out, d_in, total,
+                       planes, save_mean, save_invstd, weight, grad_mean, kcoef, leakiness);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }
