@@ -121,12 +121,13 @@ __device__ __forceinline__ void roi_wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__global__ __launch_bounds__(256) void k_roi_sparse(
+static constexpr int kRoiWaves = 4;  // waves per RoI (8 measured the same: the kernel is bandwidth-, not latency-bound)
+__global__ __launch_bounds__(kRoiWaves * 64) void k_roi_sparse(
     const HashEntry *__restrict__ tab, int cap, const float *__restrict__ feats, int C, int H, int W, int Z,
     const float *__restrict__ rois, const int32_t *__restrict__ roi_levels, int level, float spatial_scale, int PH,
     int PW, int PZ, int sampling_ratio, int layout, float *__restrict__ out) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  __shared__ int2 list[4][kRoiG][64];  // (row, weight bits) of the taps that exist
+  __shared__ int2 list[kRoiWaves][kRoiG][64];  // (row, weight bits) of the taps that exist
   const int n = blockIdx.x, cc = blockIdx.y;
   if (roi_levels && roi_levels[n] != level) return;  // pooled from another pyramid level
   const int NB = PH * PW * PZ;
@@ -138,7 +139,6 @@ __global__ __launch_bounds__(256) void k_roi_sparse(
   const bool ok0 = c0 < C, ok1 = c0 + 1 < C;
   const bool pair = ok1 && (C % 2 == 0);  // 8-byte aligned pair load
   const size_t n_out = (size_t)n;
-  const unsigned long long lt = (1ull << lane) - 1ull;
   auto load2 = [&](int row) -> f32x2 {
     const float *p = feats + (size_t)row * C + c0;
     f32x2 v = {0.f, 0.f};
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_roi_sparse(
     return v;
   };
   const int ngroups = (NB + kRoiG - 1) / kRoiG;
-  for (int grp = wave; grp < ngroups; grp += 4) {
+  for (int grp = wave; grp < ngroups; grp += kRoiWaves) {
     const int b0 = grp * kRoiG;
     f32x2 acc[kRoiG];
 #pragma unroll
@@ -180,15 +180,28 @@ __global__ __launch_bounds__(256) void k_roi_sparse(
           }
         }
       }
+      // the 64 taps of a bin fall into a handful of cells (its sub-samples are a fraction of a cell apart): merge
+      // the taps of one cell (weights summed by a wave butterfly) so that each feature row is fetched once per bin
+      // and step -- the kernel is bound by the L2 -> L1 bytes of those 512-B rows, not by instructions
       int cnt[kRoiG];
 #pragma unroll
       for (int gi = 0; gi < kRoiG; gi++) {
-        const unsigned long long m = __ballot(row[gi] >= 0);
-        cnt[gi] = __popcll(m);
-        if (row[gi] >= 0) list[wave][gi][__popcll(m & lt)] = make_int2(row[gi], __float_as_int(wgt[gi]));
+        unsigned long long m = __ballot(row[gi] >= 0);
+        int c = 0;
+        while (m) {
+          const int rl = __shfl(row[gi], __builtin_ctzll(m), 64);   // wave-uniform cell
+          const bool mine = row[gi] == rl;
+          float w = mine ? wgt[gi] : 0.f;
+#pragma unroll
+          for (int d = 32; d >= 1; d >>= 1) w += __shfl_xor(w, d, 64);
+          if (lane == 0) list[wave][gi][c] = make_int2(rl, __float_as_int(w));
+          c++;
+          m &= ~__ballot(mine);
+        }
+        cnt[gi] = c;
       }
       roi_wave_sync();
-      // ---- lanes = channel pairs: taps in (sub-sample, corner) order, batches of independent row loads ----
+      // ---- lanes = channel pairs: one entry per cell, batches of independent row loads ----
 #pragma unroll
       for (int gi = 0; gi < kRoiG; gi++) {
         const int2 *L = list[wave][gi];
@@ -368,7 +381,7 @@ int d3d_roi_align_rotated_3d_sparse_forward(d3d_meta *m, const int *size, const 
   D3D_REQUIRE(feats && rois && out, "roi_align_sparse: null pointer");
   D3D_REQUIRE(layout == 0 || layout == 1, "roi_align_sparse: layout must be 0 ([K,C,ph,pw,pz]) or 1 ([K,ph,pw,C,pz])");
   const Grid &g = it->second;
-  hipLaunchKernelGGL(k_roi_sparse, dim3(K, (C + kRoiCch - 1) / kRoiCch), dim3(256), 0, s, g.tab, g.cap, feats, C,
+  hipLaunchKernelGGL(k_roi_sparse, dim3(K, (C + kRoiCch - 1) / kRoiCch), dim3(kRoiWaves * 64), 0, s, g.tab, g.cap, feats, C,
                      crop[0], crop[1], crop[2], rois, roi_levels, level, spatial_scale, ph, pw, pz, sampling_ratio, layout, out);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
