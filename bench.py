@@ -69,7 +69,7 @@ def kernel_name(key):
     cin, cout = key
     cp = next(c for c in (16, 32, 64, 128, 256) if cin <= c)
     ct, nct = min(cp, 128), max(cp // 128, 1)
-    return (f"d3d::k_conv<{ct}, {nct}, {cout}, 1, {4 if cout == 32 else 1}, 1, {'true' if cin == cp else 'false'}> "
+    return (f"d3d::k_conv<{ct}, {nct}, {cout}, 1, {4 if cout == 32 else 1}, {'true' if cin == cp else 'false'}> "
             f"(Cin={cin}, Cout={cout}, all filter volumes)")
 
 

@@ -58,33 +58,37 @@ __global__ void k_pack_weight(const float *__restrict__ w, int fv, int cin, int 
 
 // CT   = Cin tile staged in LDS per step (multiple of 8, <= 128); NCT tiles cover Cin
 // NT   = 32-column accumulator tiles per wave; a row block is shared by WPBLK = COUT/32/NT waves
-// BPW  = row groups per workgroup (only with WPBLK == 1, where waves never synchronise)
-// MT   = 32-row blocks per wave ("row group"): the B fragments of a step (packed weights, re-fetched from
-//        L2 by every wave) are used for MT * 32 rows, which divides the dominant L2 -> L1 traffic by MT
-// VEC  = Cin equals the padded CT * NCT (16-byte row pieces): branch-free gather
-template <int CT, int NCT, int COUT, int NT, int BPW, int MT, bool VEC>
+// BPW  = row blocks per workgroup (only with WPBLK == 1, where waves never synchronise)
+// VEC  = Cin equals the padded CT * NCT (16-byte row pieces): branch-free, VALU-lean gather
+//
+// The fp32 MFMA shares the SIMD's vector ALU with ordinary VALU instructions (scripts/mfma_probe.hip: every VALU
+// instruction issued by ANY wave of the SIMD takes ~3.5 cycles away from the matrix pipe, nothing co-executes), so
+// the gather costs as few VALU instructions as possible: wave-uniform (scalar) base pointers + 32-bit per-lane byte
+// offsets, one multiplier per row (1 = real, 0 = absent neighbour) instead of per-element selects, fused multiply-add
+// + max for the BatchNorm + ReLU prologue.
+template <int CT, int NCT, int COUT, int NT, int BPW, bool VEC>
 __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
     const float *__restrict__ in, int cin, const float *__restrict__ wp,
     const int32_t *__restrict__ nbrT, int npos, const int32_t *__restrict__ rows,
     const uint32_t *__restrict__ blkmask, int n_blk, const float *__restrict__ residual,
     float *__restrict__ out, int n_split, float *__restrict__ partial, BnPre pre) {
   constexpr int WPBLK = COUT / 32 / NT;
-  static_assert(WPBLK == 1 || BPW == 1, "row groups sharing a workgroup must be single-wave");
-  static_assert(MT == 1 || BPW == 1, "multi-block row groups take a whole workgroup");
-  constexpr int TPB = WPBLK * 64;  // threads working on one row group
+  static_assert(WPBLK == 1 || BPW == 1, "row blocks sharing a workgroup must be single-wave");
+  constexpr int TPB = WPBLK * 64;  // threads working on one row block
   constexpr int LDA = CT + 4;      // +4 dwords: conflict-free ds_read_b128 of 32 rows
   constexpr int CP = CT * NCT;
   constexpr int LPR = CT / 4;      // threads per gathered row (16 B each)
   constexpr int RPP = TPB / LPR;   // rows per gather pass
-  constexpr int GR = 32 * MT;      // rows of a group
-  constexpr int NIT = (GR / RPP) > 0 ? (GR / RPP) : 1;
-  __shared__ __attribute__((aligned(16))) float smem[BPW * GR * LDA];
+  constexpr int NIT = (32 / RPP) > 0 ? (32 / RPP) : 1;
+  constexpr int NQ = CT / 8;       // q-iterations (4 MFMAs per accumulator tile each) of a step
+  constexpr int QA = NQ < 4 ? NQ : 4;  // weight fragments in flight (ring)
+  static_assert(NQ % QA == 0, "ring depth must divide the q-iterations of a step");
+  __shared__ __attribute__((aligned(16))) float smem[BPW * 32 * LDA];
 
   const int slot = threadIdx.x / TPB, tib = threadIdx.x % TPB;
-  const int grp = blockIdx.x * BPW + slot;
-  const int blk0 = grp * MT;  // first 32-row block of the group
-  if (blk0 >= n_blk) return;  // BPW > 1 only when waves are independent (no barrier below)
-  float *As = smem + slot * GR * LDA;
+  const int blk = blockIdx.x * BPW + slot;
+  if (blk >= n_blk) return;  // BPW > 1 only when waves are independent (no barrier below)
+  float *As = smem + slot * 32 * LDA;
   const int lane = tib & 63, wib = tib >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int grow = tib / LPR, gc4 = tib % LPR;
@@ -97,14 +101,9 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
       __syncthreads();
   };
 
-  uint32_t sub[MT];  // active offsets of each 32-row block of the group
-  uint32_t mask = 0;
-#pragma unroll
-  for (int m = 0; m < MT; m++) {
-    // wave-uniform: keep it (and with it k, the weight / index base pointers and the loop control) in SGPRs
-    sub[m] = __builtin_amdgcn_readfirstlane(blk0 + m < n_blk ? blkmask[blk0 + m] : 0u);
-    mask |= sub[m];
-  }
+  // active offsets of the block; wave-uniform: keep it (and with it k, the weight / index base pointers and the loop
+  // control) in SGPRs
+  uint32_t mask = __builtin_amdgcn_readfirstlane(blkmask[blk]);
   if (n_split > 1) {
     // offset-split launch (few rows): this workgroup keeps every n_split-th active offset and
     // writes a partial tile; k_conv_reduce sums the partials in a fixed order.
@@ -114,27 +113,24 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
       if (ord % n_split == (int)blockIdx.y) keep |= m & (~m + 1);
     mask = keep;
   }
-  int rowid[MT];
-  f32x16 acc[MT][NT];
+  const int rowid = rows[blk * 32 + r];
+  f32x16 acc[NT];
 #pragma unroll
-  for (int m = 0; m < MT; m++) {
-    rowid[m] = blk0 + m < n_blk ? rows[(blk0 + m) * 32 + r] : -1;
+  for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-      for (int i = 0; i < 16; i++) acc[m][nt][i] = 0.f;
-  }
+    for (int i = 0; i < 16; i++) acc[nt][i] = 0.f;
 
-  const int p0 = blk0 * 32;  // first plan position of the group
-  const int32_t *nb = nbrT + p0;
+  const int32_t *nb = nbrT + (size_t)blk * 32;
   // Gather of (offset k, Cin tile ct) in two independent waves of loads, both issued ahead of their use:
   //   load_idx(k)   : the NIT input-row indices this thread needs for offset k   (one step before issue_data)
   //   issue_data(ct): the 16-byte row pieces, branch-free -- an absent neighbour reads row 0 and is zeroed
-  //                   at commit time (stage_real), so that no load waits for another one
+  //                   at commit time, so that no load waits for another one
   //   commit_gather : registers -> LDS (+ the fused BatchNorm), after the previous step's MFMAs
   int idx[NIT];
   f32x4 stage[NIT];
-  // optional fused BatchNorm + leaky ReLU of the producer layer (y = leaky(x*w + b), applied to real rows
+  float mreal[NIT];  // 1.f for a real row, 0.f for an absent one
+  int stage_ct = 0;
+  // optional fused BatchNorm + leaky ReLU of the producer layer (y = leaky(fma(x, w, b)), applied to real rows
   // only: a missing neighbour contributes zeros, as a zero row of the normalised tensor would not);
   // this thread always gathers the same 4 channels of a Cin tile, so w and b are fetched once
   f32x4 bnw[NCT], bnb[NCT];
@@ -152,95 +148,49 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
       bnb[t] = -mu * bnw[t] + be;
     }
   }
-  // The fp32 MFMA shares the SIMD's vector ALU with ordinary VALU instructions (scripts/mfma_probe.hip: every VALU
-  // instruction issued by ANY wave of the SIMD takes ~3.5 cycles away from the matrix pipe, nothing co-executes),
-  // so the gather is written to cost as few VALU instructions as possible: wave-uniform (scalar) base pointers +
-  // 32-bit per-lane byte offsets, one multiplier per row (1 = real, 0 = absent neighbour) instead of per-element
-  // selects, fused multiply-add + max for the BatchNorm + ReLU prologue.
-  uint32_t stage_real = 0;  // (generic path) bit it: stage[it] holds a real row
-  float mreal[NIT];         // (fast path) 1.f for a real row, 0.f for an absent one
-  int stage_ct = 0;
-  uint32_t idx_on = 0;  // (generic path) bit it: idx[it] is a real plan entry
-  constexpr bool FAST = VEC && MT == 1 && (32 % RPP == 0);
   const uint32_t lane_piece = (uint32_t)gc4 * 16u, lane_idx = (uint32_t)grow * 4u;
   auto load_idx = [&](int k) {
-    if constexpr (FAST) {
-      const char *kb = (const char *)(nb + (size_t)k * npos);  // wave-uniform
+    const char *kb = (const char *)(nb + (size_t)k * npos);  // wave-uniform
 #pragma unroll
-      for (int it = 0; it < NIT; it++) idx[it] = *(const int32_t *)(kb + (lane_idx + (uint32_t)(it * RPP * 4)));
-    } else {
-      idx_on = 0;
-#pragma unroll
-      for (int it = 0; it < NIT; it++) {
-        const int row = it * RPP + grow;
-        const int mb = (32 % RPP == 0) ? (it * RPP) / 32 : (row >> 5);  // compile-time when a pass stays in one block
-        const bool on = row < GR && p0 + row < npos && ((sub[mb < MT ? mb : 0] >> k) & 1u);
-        idx[it] = nb[(size_t)k * npos + (on ? row : 0)];
-        idx_on |= (on ? 1u : 0u) << it;
+    for (int it = 0; it < NIT; it++) {
+      if constexpr (RPP <= 32) {
+        idx[it] = *(const int32_t *)(kb + (lane_idx + (uint32_t)(it * RPP * 4)));
+      } else {  // a pass wider than the block (tiny Cin tile, many waves): threads past row 31 idle
+        idx[it] = grow < 32 ? *(const int32_t *)(kb + lane_idx) : -1;
       }
     }
   };
   auto issue_data = [&](int ct) {
     stage_ct = ct;
-    if constexpr (FAST) {
-      const char *base = (const char *)(in + ct * CT);  // wave-uniform; rows are CP * 4 bytes (< 4 GiB tensor)
 #pragma unroll
-      for (int it = 0; it < NIT; it++) {
-        const int s = idx[it];
-        mreal[it] = s >= 0 ? 1.f : 0.f;
-        const uint32_t off = (uint32_t)(s < 0 ? 0 : s) * (uint32_t)(CP * 4) + lane_piece;
-        stage[it] = *(const f32x4 *)(base + off);
-      }
-    } else {
-      stage_real = 0;
-#pragma unroll
-      for (int it = 0; it < NIT; it++) {
-        const int s = ((idx_on >> it) & 1u) ? idx[it] : -1;
+    for (int it = 0; it < NIT; it++) {
+      const int s = idx[it];
+      mreal[it] = s >= 0 ? 1.f : 0.f;
+      if constexpr (VEC) {
+        const char *base = (const char *)(in + ct * CT);  // wave-uniform; rows are CP * 4 bytes (< 4 GiB tensor)
+        stage[it] = *(const f32x4 *)(base + ((uint32_t)(s < 0 ? 0 : s) * (uint32_t)(CP * 4) + lane_piece));
+      } else {
         const float *p = in + (size_t)(s < 0 ? 0 : s) * cin + ct * CT + gc4 * 4;
-        if (s >= 0) stage_real |= 1u << it;
-        if constexpr (VEC) {
-          stage[it] = *(const f32x4 *)p;
-        } else {
-          const int c = ct * CT + gc4 * 4;
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (c + 0 < cin) v[0] = p[0];
-          if (c + 1 < cin) v[1] = p[1];
-          if (c + 2 < cin) v[2] = p[2];
-          if (c + 3 < cin) v[3] = p[3];
-          stage[it] = v;
-        }
+        const int c = ct * CT + gc4 * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c + 0 < cin) v[0] = p[0];
+        if (c + 1 < cin) v[1] = p[1];
+        if (c + 2 < cin) v[2] = p[2];
+        if (c + 3 < cin) v[3] = p[3];
+        stage[it] = v;
       }
     }
   };
   auto commit_gather = [&]() {
     const f32x4 bw = stage_ct == 0 ? bnw[0] : bnw[NCT - 1], bb = stage_ct == 0 ? bnb[0] : bnb[NCT - 1];
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
       const int row = it * RPP + grow;
       f32x4 v = stage[it];
       if (pre.mean) v = bn_act(v, bw, bb, pre.leak);
-      if constexpr (FAST)
-        v = v * mreal[it];
-      else
-        v = ((stage_real >> it) & 1u) ? v : zero;
-      if (row < GR) *(f32x4 *)(As + row * LDA + gc4 * 4) = v;
+      v = v * mreal[it];
+      if (row < 32) *(f32x4 *)(As + row * LDA + gc4 * 4) = v;
     }
-  };
-
-  // B fragments (packed weights) of one (offset, Cin tile) step; with PREB they are fetched one step
-  // ahead as well, so that the L2 latency hides under the previous step's MFMAs (small Cin tiles only:
-  // the register cost is NT * CT/8 float4)
-  constexpr bool PREB = false;  // measured: the double-buffered prefetch costs 64 VGPRs = one wave of occupancy
-  constexpr int NQ = CT / 8;
-  f32x4 bcur[PREB ? NQ * NT : 1], bnext[PREB ? NQ * NT : 1];
-  auto load_b = [&](f32x4 *dst, int k, int ct) {
-    const float *wk = wp + ((size_t)(k * (CP / 4) + ct * (CT / 4)) * COUT + colbase) * 4;
-#pragma unroll
-    for (int q = 0; q < NQ; q++)
-#pragma unroll
-      for (int nt = 0; nt < NT; nt++)
-        dst[q * NT + nt] = *(const f32x4 *)(wk + ((size_t)(2 * q + h) * COUT + nt * 32 + r) * 4);
   };
 
   // step tokens: (offset k, Cin tile ct) in increasing (k, ct) order over the active offsets
@@ -250,28 +200,22 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
   };
   int k = mask ? __builtin_ctz(mask) : -1;
   int ct = 0;
-  int k_idx = -1;  // offset whose indices `idx` holds (or is loading)
+  // weight fragments (packed weights, L2-resident, shared by every block) come through a ring of QA q-iterations
+  // in flight that runs across step boundaries: the last QA refills of a step fetch the first fragments of the
+  // next one (the compiler alone keeps only ~1 load ahead)
+  f32x4 ring[QA][NT];
+  const uint32_t lane_b = (uint32_t)(h * COUT + r) * 16u;   // this lane's byte offset inside a weight fragment row
   if (k >= 0) {
     load_idx(k);
     issue_data(0);
-    if constexpr (PREB) load_b(bcur, k, 0);
-    // indices of the step after this one
-    k_idx = NCT > 1 ? k : next_k(k);
-    if (k_idx >= 0 && k_idx != k) load_idx(k_idx);
-  }
-  constexpr int QA = PREB ? 1 : (NQ < 4 ? NQ : 4);
-  static_assert(NQ % QA == 0, "ring depth must divide the q-iterations of a step");
-  f32x4 ring[QA][NT];
-  const uint32_t lane_b = (uint32_t)(h * COUT + r) * 16u;   // this lane's byte offset inside a weight fragment row
-  if constexpr (!PREB) {
-    if (k >= 0) {
-      const char *wk0 = (const char *)(wp + ((size_t)(k * (CP / 4)) * COUT + colbase) * 4);
+    const int k_after = NCT > 1 ? k : next_k(k);   // indices of the step after this one
+    if (k_after >= 0 && k_after != k) load_idx(k_after);
+    const char *wk0 = (const char *)(wp + ((size_t)(k * (CP / 4)) * COUT + colbase) * 4);
 #pragma unroll
-      for (int q = 0; q < QA; q++)
+    for (int q = 0; q < QA; q++)
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++)
-          ring[q][nt] = *(const f32x4 *)(wk0 + (lane_b + (uint32_t)((2 * q * COUT + nt * 32) * 16)));
-    }
+      for (int nt = 0; nt < NT; nt++)
+        ring[q][nt] = *(const f32x4 *)(wk0 + (lane_b + (uint32_t)((2 * q * COUT + nt * 32) * 16)));
   }
   while (k >= 0) {
     commit_gather();
@@ -284,111 +228,83 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
     }
     if (nk >= 0) {
       issue_data(nct);  // loads fly while the matrix cores work; idx holds offset nk
-      if constexpr (PREB) load_b(bnext, nk, nct);
-      // the step after that: its indices are requested now
-      const int k2 = (nct + 1 < NCT) ? nk : next_k(nk);
+      const int k2 = (nct + 1 < NCT) ? nk : next_k(nk);   // the step after that: its indices are requested now
       if (k2 >= 0 && k2 != nk) load_idx(k2);
     }
-    // ---- (MT*32) x (NT*32) += A[MT*32 x CT] * W[k][CT x cols] ----
-    const float *wk = wp + ((size_t)(k * (CP / 4) + ct * (CT / 4)) * COUT + colbase) * 4;
-    // without PREB the fragments come through a ring of QA q-iterations in flight that runs across step
-    // boundaries: the last QA refills of a step fetch the first fragments of the next one (L2 latency is a few
-    // MFMA groups long; the compiler alone keeps only ~1 load ahead)
-    const float *wk_next = nk >= 0 ? wp + ((size_t)(nk * (CP / 4) + nct * (CT / 4)) * COUT + colbase) * 4 : wk;
+    // ---- 32 x (NT*32) += A[32 x CT] * W[k][CT x cols] ----
+    const char *wk = (const char *)(wp + ((size_t)(k * (CP / 4) + ct * (CT / 4)) * COUT + colbase) * 4);
+    const char *wk_next = nk >= 0 ? (const char *)(wp + ((size_t)(nk * (CP / 4) + nct * (CT / 4)) * COUT + colbase) * 4) : wk;
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
       f32x4 b[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; nt++) {
-        if constexpr (PREB)
-          b[nt] = bcur[q * NT + nt];
-        else
-          b[nt] = ring[q % QA][nt];
-      }
-      if constexpr (!PREB) {
-        const char *src = (const char *)((q + QA < NQ) ? wk : wk_next);   // wave-uniform base + per-lane byte offset
+      for (int nt = 0; nt < NT; nt++) b[nt] = ring[q % QA][nt];
+      {
+        const char *src = (q + QA < NQ) ? wk : wk_next;   // wave-uniform base + per-lane byte offset
         const int qq = (q + QA) % NQ;
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
           ring[q % QA][nt] = *(const f32x4 *)(src + (lane_b + (uint32_t)((2 * qq * COUT + nt * 32) * 16)));
       }
+      const f32x4 a = *(const f32x4 *)(As + r * LDA + q * 8 + h * 4);
 #pragma unroll
-      for (int m = 0; m < MT; m++) {
-        if (MT > 1 && !((sub[m] >> k) & 1u)) continue;  // wave-uniform: this block has no rule at offset k
-        const f32x4 a = *(const f32x4 *)(As + (m * 32 + r) * LDA + q * 8 + h * 4);
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) {
-          acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[nt][0], acc[m][nt], 0, 0, 0);
-          acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[nt][1], acc[m][nt], 0, 0, 0);
-          acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[nt][2], acc[m][nt], 0, 0, 0);
-          acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[nt][3], acc[m][nt], 0, 0, 0);
-        }
+      for (int nt = 0; nt < NT; nt++) {
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[nt][0], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[nt][1], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[nt][2], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[nt][3], acc[nt], 0, 0, 0);
       }
     }
-    if constexpr (!PREB && MT == 1) {
-      // order of the step's instruction stream: the gather / index / first ring loads up front, then per q-iteration
-      // one LDS read (A of the next iteration), the MFMA group, one weight load (ring refill QA iterations ahead)
-      __builtin_amdgcn_sched_group_barrier(0x020, 2 * NIT, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    // order of the step's instruction stream: the gather / index loads up front, then per q-iteration one MFMA,
+    // one LDS read (A of the next iteration), one weight load (ring refill QA iterations ahead), the other MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x020, 2 * NIT, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
-      for (int q = 0; q < NQ; q++) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, NT, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT - 1, 0);
-      }
+    for (int q = 0; q < NQ; q++) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, NT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT - 1, 0);
     }
     block_sync();
-    if constexpr (PREB) {
-      // keep the register copy (and the wait for the prefetched fragments it implies) behind the MFMAs: the
-      // scheduler otherwise interleaves it with them and the loads issued above are waited for at once
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < NQ * NT; i++) bcur[i] = bnext[i];
-    }
     k = nk;
     ct = nct;
   }
   // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
   if (n_split > 1) {
-    if constexpr (MT == 1) {
-      float *pt = partial + ((size_t)blockIdx.y * npos + (size_t)blk0 * 32) * COUT;
+    float *pt = partial + ((size_t)blockIdx.y * npos + (size_t)blk * 32) * COUT;
 #pragma unroll
-      for (int reg = 0; reg < 16; reg++) {
-        const int row_in = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    for (int reg = 0; reg < 16; reg++) {
+      const int row_in = (reg & 3) + 8 * (reg >> 2) + 4 * h;
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++) pt[(size_t)row_in * COUT + colbase + nt * 32 + r] = acc[0][nt][reg];
-      }
+      for (int nt = 0; nt < NT; nt++) pt[(size_t)row_in * COUT + colbase + nt * 32 + r] = acc[nt][reg];
     }
     return;
   }
+  // four rows at a time: residual reads first (a padded row reads row 0 and is dropped), then adds and stores --
+  // no load waits for another, and the epilogue does not set the kernel's register budget
 #pragma unroll
-  for (int m = 0; m < MT; m++) {
-    // four rows at a time: residual reads first (a padded row reads row 0 and is dropped), then adds and stores --
-    // no load waits for another, and the epilogue does not set the kernel's register budget
+  for (int g4 = 0; g4 < 4; g4++) {
+    int orow[4];
+    float res[4][NT];
 #pragma unroll
-    for (int g4 = 0; g4 < 4; g4++) {
-      int orow[4];
-      float res[4][NT];
+    for (int j = 0; j < 4; j++) orow[j] = __shfl(rowid, j + 8 * g4 + 4 * h, 64);
+    if (residual) {
 #pragma unroll
-      for (int j = 0; j < 4; j++) orow[j] = __shfl(rowid[m], j + 8 * g4 + 4 * h, 64);
-      if (residual) {
+      for (int j = 0; j < 4; j++)
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int nt = 0; nt < NT; nt++)
+          res[j][nt] = residual[(size_t)(orow[j] < 0 ? 0 : orow[j]) * COUT + colbase + nt * 32 + r];
 #pragma unroll
-          for (int nt = 0; nt < NT; nt++)
-            res[j][nt] = residual[(size_t)(orow[j] < 0 ? 0 : orow[j]) * COUT + colbase + nt * 32 + r];
+      for (int j = 0; j < 4; j++)
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int nt = 0; nt < NT; nt++) acc[nt][g4 * 4 + j] += res[j][nt];
+    }
 #pragma unroll
-          for (int nt = 0; nt < NT; nt++) acc[m][nt][g4 * 4 + j] += res[j][nt];
-      }
+    for (int j = 0; j < 4; j++) {
+      if (orow[j] < 0) continue;
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        if (orow[j] < 0) continue;
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) out[(size_t)orow[j] * COUT + colbase + nt * 32 + r] = acc[m][nt][g4 * 4 + j];
-      }
+      for (int nt = 0; nt < NT; nt++) out[(size_t)orow[j] * COUT + colbase + nt * 32 + r] = acc[nt][g4 * 4 + j];
     }
   }
 }
@@ -412,27 +328,11 @@ __global__ __launch_bounds__(256) void k_conv_reduce(const float *__restrict__ p
 
 static constexpr int kSplitTargetWaves = 2048;  // below this many waves the launch is offset-split
 
-template <int CT, int NCT, int COUT, int NT, int BPW, int MT>
-static void launch_k(const Plan &p, const float *in, int cin, const float *wp, const float *residual, float *out,
-                     hipStream_t s, int n_split, float *partial, BnPre pre) {
-  constexpr int WPBLK = COUT / 32 / NT;
-  constexpr int threads = BPW * WPBLK * 64;
-  const int groups = (p.n_blk + MT - 1) / MT;
-  dim3 grid((groups + BPW - 1) / BPW, n_split);
-  if (cin == CT * NCT)
-    hipLaunchKernelGGL((k_conv<CT, NCT, COUT, NT, BPW, MT, true>), grid, dim3(threads), 0, s, in, cin, wp, p.nbrT,
-                       p.n_blk * 32, p.rows, p.blkmask, p.n_blk, residual, out, n_split, partial, pre);
-  else
-    hipLaunchKernelGGL((k_conv<CT, NCT, COUT, NT, BPW, MT, false>), grid, dim3(threads), 0, s, in, cin, wp, p.nbrT,
-                       p.n_blk * 32, p.rows, p.blkmask, p.n_blk, residual, out, n_split, partial, pre);
-}
-
-// (The kernel's MT > 1 row groups -- one weight fetch for 64 rows -- measured slower on the MI355X than MT = 1:
-//  the per-block skip branches break the MFMA/LDS software pipeline and occupancy halves; not instantiated.)
 template <int CT, int NCT, int COUT, int NT, int BPW>
 static int launch_t(d3d_meta *m, const Plan &p, const float *in, int cin, const float *wp,
                     const float *residual, float *out, hipStream_t s, BnPre pre) {
   constexpr int WPBLK = COUT / 32 / NT;
+  constexpr int threads = BPW * WPBLK * 64;
   const int npos = p.n_blk * 32;
   const long waves = (long)p.n_blk * WPBLK;
   int n_split = 1;
@@ -446,7 +346,13 @@ static int launch_t(d3d_meta *m, const Plan &p, const float *in, int cin, const 
     partial = m->arena.get<float>((size_t)n_split * npos * COUT);
     if (!partial) n_split = 1;  // arena full: fall back to the unsplit launch
   }
-  launch_k<CT, NCT, COUT, NT, BPW, 1>(p, in, cin, wp, residual, out, s, n_split, partial, pre);
+  const dim3 grid((p.n_blk + BPW - 1) / BPW, n_split);
+  if (cin == CT * NCT)
+    hipLaunchKernelGGL((k_conv<CT, NCT, COUT, NT, BPW, true>), grid, dim3(threads), 0, s, in, cin, wp, p.nbrT, npos,
+                       p.rows, p.blkmask, p.n_blk, residual, out, n_split, partial, pre);
+  else
+    hipLaunchKernelGGL((k_conv<CT, NCT, COUT, NT, BPW, false>), grid, dim3(threads), 0, s, in, cin, wp, p.nbrT, npos,
+                       p.rows, p.blkmask, p.n_blk, residual, out, n_split, partial, pre);
   if (n_split > 1) {
     const long total = (long)npos * (COUT / 4);
     hipLaunchKernelGGL(k_conv_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, partial, n_split,
@@ -462,7 +368,8 @@ static int launch_c(d3d_meta *m, const Plan &p, const float *in, int cin, const 
                     const float *residual, float *out, hipStream_t s, BnPre pre) {
   switch (cout) {
     case 32: return launch_t<CT, NCT, 32, 1, 4>(m, p, in, cin, wp, residual, out, s, pre);    // 4 independent waves
-    // (NT = 2 -- half as many waves per row block, no or fewer barriers -- measured slower: occupancy drops to 2)
+    // (NT = 2 -- half as many waves per row block, no or fewer barriers -- measured slower; DESIGN.md lists the other
+    //  variants that lost to this shape: 64-row groups, streaming workgroups, LDS-free A, shared weight tile)
     case 64: return launch_t<CT, NCT, 64, 1, 1>(m, p, in, cin, wp, residual, out, s, pre);    // 2 waves / block
     case 128: return launch_t<CT, NCT, 128, 1, 1>(m, p, in, cin, wp, residual, out, s, pre);  // 4 waves / block
     case 256: return launch_t<CT, NCT, 256, 1, 1>(m, p, in, cin, wp, residual, out, s, pre);  // 8 waves / block
