@@ -77,6 +77,7 @@ struct Grid {
   int cap = 0;      // hash capacity (power of two)
   HashEntry *tab = nullptr;
   int32_t *loc = nullptr;  // [n,4] x,y,z,b
+  int32_t *extent = nullptr;  // device int[3]: 1 + max coordinate per axis (filled on first use, grid_extent)
 };
 
 // BatchNorm affine + leaky ReLU on 4 channels: y = leaky(fma(x, w, b)).  ONE definition for k_bn_apply and the fused
@@ -148,6 +149,8 @@ int plan_rules(d3d_meta *m, Plan &p, hipStream_t s, long *out);
 const Plan *find_plan(d3d_meta *m, int kind, const int *in_size, const int *filt, const int *stride);
 int get_deconv_plan(d3d_meta *m, const int *fine_size, const int *filt, const int *stride,
                     hipStream_t s, const Plan **out);
+
+int grid_extent(d3d_meta *m, Grid &g, hipStream_t s);  // grid.hip: ensures g.extent
 
 // conv.hip
 int launch_conv(d3d_meta *m, const Plan &p, const float *in, int cin, const float *packed_w, int cout,

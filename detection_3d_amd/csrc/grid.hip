@@ -566,6 +566,33 @@ int get_deconv_plan(d3d_meta *m, const int *fine_size, const int *filt, const in
   return D3D_OK;
 }
 
+// occupied extent of a grid (1 + max coordinate per axis), what sparse_3d_to_dense_2d crops the dense map to
+__global__ void k_grid_extent(const int32_t *__restrict__ loc, int n, int32_t *__restrict__ extent) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int v[3] = {0, 0, 0};
+  if (i < n) {
+    v[0] = loc[(size_t)i * 4] + 1;
+    v[1] = loc[(size_t)i * 4 + 1] + 1;
+    v[2] = loc[(size_t)i * 4 + 2] + 1;
+  }
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    int m = v[d];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&extent[d], m);
+  }
+}
+int grid_extent(d3d_meta *m, Grid &g, hipStream_t s) {
+  if (g.extent) return D3D_OK;
+  D3D_ALLOC(e, int32_t, m->arena, 4);
+  D3D_HIP_CHECK(hipMemsetAsync(e, 0, 4 * sizeof(int32_t), s));
+  if (g.n > 0) hipLaunchKernelGGL(k_grid_extent, grid1d(g.n), dim3(256), 0, s, g.loc, g.n, e);
+  D3D_LAUNCH_CHECK();
+  g.extent = e;
+  return D3D_OK;
+}
+
 __global__ void k_locations(const int32_t *__restrict__ loc, int n, int64_t *__restrict__ out) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n * 4) out[t] = loc[t];

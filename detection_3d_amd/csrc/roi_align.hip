@@ -124,8 +124,13 @@ __device__ __forceinline__ void roi_wave_sync() {
 static constexpr int kRoiWaves = 4;  // waves per RoI (8 measured the same: the kernel is bandwidth-, not latency-bound)
 __global__ __launch_bounds__(kRoiWaves * 64) void k_roi_sparse(
     const HashEntry *__restrict__ tab, int cap, const float *__restrict__ feats, int C, int H, int W, int Z,
-    const float *__restrict__ rois, const int32_t *__restrict__ roi_levels, int level, float spatial_scale, int PH,
-    int PW, int PZ, int sampling_ratio, int layout, float *__restrict__ out) {
+    const int32_t *__restrict__ extent, const float *__restrict__ rois, const int32_t *__restrict__ roi_levels,
+    int level, float spatial_scale, int PH, int PW, int PZ, int sampling_ratio, int layout, float *__restrict__ out) {
+  if (extent) {  // crop = occupied extent of the grid, read on the device (no host round trip)
+    H = extent[0];
+    W = extent[1];
+    Z = extent[2];
+  }
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   __shared__ int2 list[kRoiWaves][kRoiG][64];  // (row, weight bits) of the taps that exist
   const int n = blockIdx.x, cc = blockIdx.y;
@@ -371,7 +376,7 @@ int d3d_roi_align_rotated_3d_sparse_forward(d3d_meta *m, const int *size, const 
                                             int sampling_ratio, const int *roi_levels, int level, int layout,
                                             float *out, void *stream) {
   hipStream_t s = (hipStream_t)stream;
-  D3D_REQUIRE(m && size && crop && C > 0 && K >= 0 && ph > 0 && pw > 0 && pz > 0, "roi_align_sparse: bad arguments");
+  D3D_REQUIRE(m && size && C > 0 && K >= 0 && ph > 0 && pw > 0 && pz > 0, "roi_align_sparse: bad arguments");
   auto it = m->grids.find(Size3{size[0], size[1], size[2]});
   if (it == m->grids.end()) {
     set_error("roi_align_sparse: no grid of spatial size [%d,%d,%d]", size[0], size[1], size[2]);
@@ -380,9 +385,16 @@ int d3d_roi_align_rotated_3d_sparse_forward(d3d_meta *m, const int *size, const 
   if (K == 0) return D3D_OK;
   D3D_REQUIRE(feats && rois && out, "roi_align_sparse: null pointer");
   D3D_REQUIRE(layout == 0 || layout == 1, "roi_align_sparse: layout must be 0 ([K,C,ph,pw,pz]) or 1 ([K,ph,pw,C,pz])");
-  const Grid &g = it->second;
+  Grid &g = it->second;
+  const int32_t *extent = nullptr;
+  if (!crop) {  // NULL crop: the grid's own occupied extent, computed once on the device
+    int rc = grid_extent(m, g, s);
+    if (rc) return rc;
+    extent = g.extent;
+  }
   hipLaunchKernelGGL(k_roi_sparse, dim3(K, (C + kRoiCch - 1) / kRoiCch), dim3(kRoiWaves * 64), 0, s, g.tab, g.cap, feats, C,
-                     crop[0], crop[1], crop[2], rois, roi_levels, level, spatial_scale, ph, pw, pz, sampling_ratio, layout, out);
+                     crop ? crop[0] : 0, crop ? crop[1] : 0, crop ? crop[2] : 0, extent, rois, roi_levels, level,
+                     spatial_scale, ph, pw, pz, sampling_ratio, layout, out);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }

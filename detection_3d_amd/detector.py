@@ -270,14 +270,13 @@ class Pooler(nn.Module):
             rois = convert_to_roi_format(boxes_pixels)
         ph, pw, pz = self.output_size
         if not torch.is_grad_enabled():
-            # one result tensor filled in place by one launch per level (no nonzero / index_put, one host sync)
+            # one result tensor filled in place by one launch per level (no nonzero / index_put, no host sync)
             K, C = rois.shape[0], x[0].features.shape[1]
             out = torch.empty((K, ph, pw, C, pz) if channels_inner else (K, C, ph, pw, pz), dtype=torch.float32,
                               device=rois.device)
             levels = self.map_levels(boxes_pixels).to(torch.int32) if len(self.scales) > 1 else None
-            crops = (torch.stack([f.get_spatial_locations()[:, :3].max(0)[0] for f in x]) + 1).tolist()
-            for level, (fmap, scale) in enumerate(zip(x, self.scales)):
-                roi_align_rotated_3d_sparse_into(out, fmap, rois, scale, self.sampling_ratio, crop=crops[level],
+            for level, (fmap, scale) in enumerate(zip(x, self.scales)):   # crop = occupied extent, found on the device
+                roi_align_rotated_3d_sparse_into(out, fmap, rois, scale, self.sampling_ratio, crop=None,
                                                  roi_levels=levels, level=level, channels_inner=channels_inner)
             return out
         assert not channels_inner
@@ -413,13 +412,16 @@ class PostProcessor(nn.Module):
         keep, nk = box_ops.nms_3d_batched(boxes.view(-1, 7), order, counts, n_max, self.nms, self.nms_aug_thickness,
                                           500)                                   # post_max_size (boxlist_ops_3d.py)
         valid = torch.arange(keep.shape[1], device=prob.device).view(1, -1) < nk.view(-1, 1)
-        flat = keep[valid].long()                                                # class-major, selection order
+        flat_all = torch.where(valid, keep, torch.zeros_like(keep)).long().view(-1)   # class-major, selection order
+        s_all = torch.where(valid.view(-1), prob.reshape(-1)[flat_all], prob.new_full((), -1.0))
+        if 0 < self.detections_per_img < s_all.shape[0]:                         # :140-148 without a second read-back:
+            # kthvalue(s, n - D + 1) is the D-th largest score; with fewer than D survivors it is a padding entry (-1)
+            thresh = torch.topk(s_all, self.detections_per_img, sorted=True)[0][-1]
+            sel = valid.view(-1) & (s_all >= thresh)
+        else:
+            sel = valid.view(-1)
+        flat = flat_all[sel]                                                     # the one host synchronisation
         b, s, l = boxes.view(-1, 7)[flat], prob.reshape(-1)[flat], flat % nc
-        n = s.shape[0]
-        if n > self.detections_per_img > 0:                                      # :140-148
-            thresh = torch.kthvalue(s, n - self.detections_per_img + 1)[0]
-            keep = torch.nonzero(s >= thresh).squeeze(1)
-            b, s, l = b[keep], s[keep], l[keep]
         return {"bbox3d": b, "scores": s, "labels": l}
 
 

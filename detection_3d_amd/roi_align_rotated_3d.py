@@ -106,13 +106,12 @@ def roi_align_rotated_3d_sparse_into(out, feat_s3d, rois, spatial_scale, samplin
     else:
         _, C, ph, pw, pz = out.shape
     assert C == f.shape[1]
-    if crop is None:
-        loc = feat_s3d.get_spatial_locations()
-        crop = (loc[:, :3].max(0)[0] + 1).tolist()
     if roi_levels is not None:
         assert roi_levels.dtype == torch.int32 and roi_levels.is_contiguous() and roi_levels.shape[0] == r.shape[0]
+    # crop None: the library finds the occupied extent of the map on the device (no host read-back)
     check(lib().d3d_roi_align_rotated_3d_sparse_forward(
-        feat_s3d.metadata._h, ints(feat_s3d.spatial_size.tolist()), ptr(f), C, ints([int(c) for c in crop]), ptr(r),
+        feat_s3d.metadata._h, ints(feat_s3d.spatial_size.tolist()), ptr(f), C,
+        None if crop is None else ints([int(c) for c in crop]), ptr(r),
         r.shape[0], float(spatial_scale), ph, pw, pz, int(sampling_ratio), ptr(roi_levels), int(level),
         1 if channels_inner else 0, ptr(out), stream_of()))
     return out

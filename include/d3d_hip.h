@@ -213,7 +213,8 @@ int d3d_roi_align_rotated_3d_forward(const float *input, int B, int C, int H, in
                                      int pz, int sampling_ratio, float *out, void *stream);
 /* Same result sampled straight from the sparse tensor through the hash grid (no 1 GB dense
  * map): equals sparse_3d_to_dense_2d (sparseconvnet/tools_3d_2d.py:7-48, crop to the occupied
- * extent crop_host[3]) followed by the dense op.
+ * extent crop_host[3]; NULL: the extent of the grid itself, found on the device without a host read-back)
+ * followed by the dense op.
  * roi_levels (device int32[K], nullable): only RoIs with roi_levels[i] == level are pooled, the other output
  * slots are left untouched, so that the per-level calls of poolers_3d.py:150-168 fill one result tensor
  * without nonzero / index / index_put passes.
