@@ -230,3 +230,48 @@ def test_bn_prologue_fusion_is_bit_identical(dev):
     assert len(outs[0]) == len(outs[1]) > 0
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n_sites", [1, 31, 32, 33, 257, 8191, 8192, 8193, 20000])
+def test_plan_and_conv_at_boundary_sizes(dev, n_sites):
+    """Row counts around the block (32), small-plan (8192) and offset-split thresholds: rulebooks exact, fused
+    BatchNorm + convolution + residual within tolerance."""
+    from detection_3d_amd import sparseconvnet as scn
+    from detection_3d_amd._lib import check, ints, lib, stream_of
+    import ctypes
+    size = (64, 64, 32)
+    rng = np.random.RandomState(n_sites)
+    # distinct voxels in a compact region (dense enough to have neighbours)
+    side = max(2, int(np.ceil((n_sites * 2.5) ** (1 / 3))))
+    cells = rng.permutation(side ** 3)[:n_sites]
+    coords = np.stack([cells // (side * side), (cells // side) % side, cells % side], 1).astype(np.int64)
+    coords = coords[(coords < np.array(size)).all(1)]
+    cin = cout = 64
+    feats = rng.randn(coords.shape[0], cin).astype(np.float32)
+    t = scn.InputLayer(3, size, mode=4)([torch.from_numpy(coords), torch.from_numpy(feats).to(dev)])
+    sop, loc = oracle.input_sites(coords)
+    assert t.features.shape[0] == loc.shape[0] == coords.shape[0]
+    x = oracle.input_forward(feats, sop, loc.shape[0], True)
+    nr = ctypes.c_long(0)
+    check(lib().d3d_subm_prepare(t.metadata._h, ints(size), ints([3, 3, 3]), stream_of(), ctypes.byref(nr)))
+    nbr, total = oracle.subm_nbr(loc, [3, 3, 3])
+    assert nr.value == total
+    assert np.array_equal(canon_rules(t.metadata.export_rules(0, size, [3, 3, 3]).cpu().numpy()),
+                          canon_rules(nbr_to_rules(nbr)))
+    torch.manual_seed(1)
+    bn = scn.BatchNormLeakyReLU(cin, momentum=0.95, leakiness=0, track_running_stats=False).to(dev).eval()
+    conv = scn.SubmanifoldConvolution(3, cin, cout, 3, False).to(dev)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+        res = torch.randn(loc.shape[0], cout, device=dev)
+        got = conv(bn(t), residual=scn.SparseConvNetTensor(res, t.metadata, t.spatial_size)).features.cpu().numpy()
+    if loc.shape[0] > 1:
+        mean = x.mean(0, dtype=np.float64).astype(np.float32)
+        var = x.var(0, ddof=1, dtype=np.float64).astype(np.float32)
+        y, *_ = oracle.bn_forward(x, mean, var, bn.weight.detach().cpu().numpy(), bn.bias.detach().cpu().numpy(), 1e-4,
+                                  0.95, False, 0.0)
+        want = oracle.nbr_conv(y, conv.weight.detach().cpu().numpy().reshape(27, cin, cout), nbr) + res.cpu().numpy()
+        assert rel_err(got, want) < 2e-4
+    else:
+        assert got.shape == (1, cout)          # one site: the unbiased variance is undefined (reference: NaN)
