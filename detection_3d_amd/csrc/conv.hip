@@ -231,6 +231,7 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
       const int k2 = (nct + 1 < NCT) ? nk : next_k(nk);   // the step after that: its indices are requested now
       if (k2 >= 0 && k2 != nk) load_idx(k2);
     }
+    __builtin_amdgcn_s_setprio(1);
     // ---- 32 x (NT*32) += A[32 x CT] * W[k][CT x cols] ----
     const char *wk = (const char *)(wp + ((size_t)(k * (CP / 4) + ct * (CT / 4)) * COUT + colbase) * 4);
     const char *wk_next = nk >= 0 ? (const char *)(wp + ((size_t)(nk * (CP / 4) + nct * (CT / 4)) * COUT + colbase) * 4) : wk;
@@ -266,6 +267,7 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
       __builtin_amdgcn_sched_group_barrier(0x020, NT, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT - 1, 0);
     }
+    __builtin_amdgcn_s_setprio(0);
     block_sync();
     k = nk;
     ct = nct;
