@@ -68,18 +68,28 @@ def calc_prec_rec(preds, gts, iou_thresh, eval_aug_thickness, iou_fn=_gpu_iou):
     return prec, rec, scores, pious
 
 
-def calc_ap(prec, rec, use_07_metric=True):
+def calc_ap(prec, rec, use_07_metric=True, scores=None, predious=None):
+    """suncg_eval.py:884-965.  -> ap [n_cls] (slot 0 = mean over the classes) and, when `scores` / `predious` are
+    given (VOC07 metric), the reference's recall-precision-score-IoU table [n_cls, 11, 4]: at recall t = 0, 0.1 .. 1
+    the best precision, the score threshold that reaches it and the best matched IoU (the 'mIoU' rows of its reports)."""
     n = len(prec)
     ap = np.empty(n)
+    table = np.full((n, 11, 4), np.nan)
     for l in range(n):
         if prec[l] is None or rec[l] is None:
             ap[l] = np.nan
             continue
         if use_07_metric:
             ap[l] = 0
-            for t in np.arange(0.0, 1.1, 0.1):
-                p = 0 if np.sum(rec[l] >= t) == 0 else np.max(np.nan_to_num(prec[l])[rec[l] >= t])
+            for j, t in enumerate(np.arange(0.0, 1.1, 0.1)):
+                reach = rec[l] >= t
+                p = 0 if np.sum(reach) == 0 else np.max(np.nan_to_num(prec[l])[reach])
                 ap[l] += p / 11
+                if scores is not None and predious is not None and scores[l] is not None:
+                    iou = 0 if np.sum(reach) == 0 else np.max(np.nan_to_num(predious[l])[reach])
+                    below = rec[l] <= t
+                    sc = np.max(scores[l]) + 0.01 if np.sum(below) == 0 else np.min(scores[l][below])
+                    table[l, j] = [t, p, sc, iou]
         else:
             mpre = np.concatenate(([0], np.nan_to_num(prec[l]), [0]))
             mrec = np.concatenate(([0], rec[l], [1]))
@@ -87,14 +97,20 @@ def calc_ap(prec, rec, use_07_metric=True):
             i = np.where(mrec[1:] != mrec[:-1])[0]
             ap[l] = np.sum((mrec[i + 1] - mrec[i]) * mpre[i + 1])
     ap[0] = np.nanmean(ap[1:]) if n > 1 else np.nan                          # class 0 slot = average (:964-965)
-    return ap
+    if n > 1:
+        with np.errstate(all="ignore"):
+            table[0] = np.nanmean(table[1:], axis=0)
+    if scores is None or predious is None:
+        return ap
+    return ap, table
 
 
 def eval_detection_suncg(preds, gts, cfg, use_07_metric=True, iou_fn=_gpu_iou):
-    """Returns {'ap': per-class AP (index 0 = mean), 'map': mean} at cfg.TEST.IOU_THRESHOLD with
+    """Returns {'ap': per-class AP (index 0 = mean), 'map': mean, 'recall_precision_score_iou': table} at cfg.TEST.IOU_THRESHOLD with
     TEST.EVAL_AUG_THICKNESS_* (maskrcnn_benchmark/config/defaults.py:318-320)."""
     ay, az = cfg.TEST.EVAL_AUG_THICKNESS_Y_TAR_ANC, cfg.TEST.EVAL_AUG_THICKNESS_Z_TAR_ANC
     aug = {'target_Y': ay[0], 'anchor_Y': ay[1], 'target_Z': az[0], 'anchor_Z': az[1]}
     prec, rec, scores, pious = calc_prec_rec(preds, gts, cfg.TEST.IOU_THRESHOLD, aug, iou_fn)
-    ap = calc_ap(prec, rec, use_07_metric)
-    return {"ap": ap, "map": float(np.nanmean(ap[1:])), "prec": prec, "rec": rec}
+    ap, table = calc_ap(prec, rec, use_07_metric, scores, pious)
+    return {"ap": ap, "map": float(np.nanmean(ap[1:])), "prec": prec, "rec": rec,
+            "recall_precision_score_iou": table}   # [n_cls, 11, 4]; [:, :, 3] are the reference's mIoU rows

@@ -46,6 +46,16 @@ def test_voc07_and_area_ap_formulas():
     ap07 = calc_ap(prec, rec, True)[1]
     assert abs(ap07 - (6 * 1.0 + 5 * 2 / 3) / 11) < 1e-9
     assert abs(calc_ap(prec, rec, False)[1] - (0.5 * 1.0 + 0.5 * 2 / 3)) < 1e-9
+    # the reference's recall-precision-score-IoU table (suncg_eval.py:915-942): hand-evaluated rows
+    scores = [None, np.array([0.9, 0.8, 0.7, 0.6])]
+    pious = [None, np.array([0.8, 0.1, 0.6, 0.2])]
+    ap, tab = calc_ap(prec, rec, True, scores, pious)
+    assert abs(ap[1] - ap07) < 1e-12 and tab.shape == (2, 11, 4)
+    assert np.allclose(tab[1, 0], [0.0, 1.0, 0.91, 0.8])            # recall 0: no rec <= 0 -> max score + 0.01
+    assert np.allclose(tab[1, 5], [0.5, 1.0, 0.8, 0.8])             # recall 0.5: lowest score with rec <= 0.5
+    assert np.allclose(tab[1, 6], [0.6, 2 / 3, 0.8, 0.6])           # only the last two predictions reach 0.6
+    assert np.allclose(tab[1, 10], [1.0, 2 / 3, 0.6, 0.6])
+    assert np.allclose(tab[0], tab[1])                               # slot 0 = class mean
 
 
 @pytest.mark.gpu
