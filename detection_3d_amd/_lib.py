@@ -137,7 +137,17 @@ def check(rc):
         raise D3DError(f"libd3d_hip error {rc}: {msg.decode() if msg else ''}")
 
 
+_INTS = {}     # tuple -> ctypes int array; the library only reads these arrays
+
+
 def ints(values):
+    if type(values) is tuple:
+        a = _INTS.get(values)
+        if a is None:
+            if len(_INTS) > 4096:
+                _INTS.clear()
+            a = _INTS[values] = (ctypes.c_int * len(values))(*values)
+        return a
     values = [int(v) for v in values]
     return (ctypes.c_int * len(values))(*values)
 
@@ -154,8 +164,21 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def raw_stream(device=None):
+    """hipStream_t of torch's current stream as an int (torch.cuda.current_stream costs ~10 us of Python per
+    call, and every library call needs the stream)."""
+    if _RAW_STREAM is None or _GET_DEVICE is None:
+        return torch.cuda.current_stream(device).cuda_stream
+    idx = None if device is None else (device if isinstance(device, int) else device.index)
+    return _RAW_STREAM(_GET_DEVICE() if idx is None else idx)
+
+
 def stream_of(device=None):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return ctypes.c_void_p(raw_stream(device))
 
 
 def require_gpu(*tensors):

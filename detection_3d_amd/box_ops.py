@@ -12,6 +12,7 @@ import math
 
 import torch
 
+from . import _lib
 from ._lib import D3DError, check, floats, lib, ptr, require_gpu, stream_of
 
 
@@ -69,14 +70,18 @@ def boxes_iou_3d(targets_bbox3d, anchors_bbox3d, aug_thickness=None, criterion=-
 _NMS_SCRATCH = {}
 
 
+def _nms_key(dev):      # one scratch per (device, stream): buildings in flight on different streams never share it
+    return (dev.index, _lib.raw_stream(dev))
+
+
 def _nms_sorted(boxes_sorted, thresh, max_keep=0):
     n = boxes_sorted.shape[0]
     dev = boxes_sorted.device
     nbytes = lib().d3d_nms_scratch_bytes(n)
-    buf = _NMS_SCRATCH.get(dev.index)
+    buf = _NMS_SCRATCH.get(_nms_key(dev))
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
-        _NMS_SCRATCH[dev.index] = buf
+        _NMS_SCRATCH[_nms_key(dev)] = buf
     keep = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     nk = torch.zeros(1, dtype=torch.int32, device=dev)
     check(lib().d3d_rotate_nms_3d_sorted(ptr(boxes_sorted), n, float(thresh), int(max_keep or 0), ptr(keep), ptr(nk),
@@ -99,10 +104,10 @@ def nms_3d_batched(boxes, order, counts, n_max, iou_threshold, aug_thickness=(0.
     if counts is not None:
         assert counts.dtype == torch.int32 and counts.is_contiguous() and counts.shape[0] == B
     nbytes = lib().d3d_nms_batched_scratch_bytes(B, n_max)
-    buf = _NMS_SCRATCH.get(dev.index)
+    buf = _NMS_SCRATCH.get(_nms_key(dev))
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
-        _NMS_SCRATCH[dev.index] = buf
+        _NMS_SCRATCH[_nms_key(dev)] = buf
     keep = torch.empty((B, max(n_max, 1)), dtype=torch.int32, device=dev)
     nk = torch.zeros(B, dtype=torch.int32, device=dev)
     check(lib().d3d_rotate_nms_3d_batched(ptr(boxes), ptr(order), stride, ptr(counts), B, n_max, float(iou_threshold),

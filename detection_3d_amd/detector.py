@@ -518,7 +518,18 @@ class SparseRCNN(nn.Module):
             return self._forward_eval(points, return_intermediates)
 
     def _forward_eval(self, points, return_intermediates=False):
-        rpn_features, roi_features = self.backbone(points)
+        return self.stage_tail(self.backbone(points), return_intermediates)
+
+    # the three stages of a pipelined inference pass (serving.BuildingPipeline); stage_tail(backbone(points)) is the
+    # plain pass
+    def stage_geometry(self, points):
+        return self.backbone.stage_geometry(points)
+
+    def stage_features(self, net):
+        return self.backbone.stage_features(net)
+
+    def stage_tail(self, features, return_intermediates=False):
+        rpn_features, roi_features = features
         out = self.rpn(rpn_features)
         proposals, objectness = out[0].clone(), out[1]
         sep_id = out[2] if len(out) == 3 else None

@@ -7,6 +7,7 @@ empty and resized by the callee), but every call lands in libd3d_hip.so on the c
 Forward and backward entry points of the ops the 3-D detection path uses.
 """
 import ctypes
+import threading
 import os
 
 import torch
@@ -16,11 +17,17 @@ from .._lib import check, ints, lib, ptr, require_gpu, stream_of
 
 _ARENA_BYTES = int(os.environ.get("D3D_ARENA_MB", "2048")) << 20
 _POOL = []          # recycled native metadata handles (one HBM arena each)
-_SCRATCH = {}       # per-device scratch tensors
+_POOL_LOCK = threading.RLock()   # re-entrant: __del__ may run inside a locked region (GC)
+_SCRATCH = {}       # scratch tensors per (device, stream): buildings in flight on different streams never share one
+
+
+def _scratch_key(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return (idx, _lib.raw_stream(idx))
 
 
 def _scratch(device, nbytes):
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    key = _scratch_key(device)
     buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 22), dtype=torch.uint8, device=device)
@@ -33,8 +40,8 @@ _BN_SCRATCH = {}
 
 def _bn_scratch(device, nbytes):
     """Scratch of the BatchNorm statistics kernels: starts with a ticket word that must be zero on entry
-    (the kernel leaves it zero), so it is zero-initialised and never shared with other ops."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    (the kernel leaves it zero), so it is zero-initialised and never shared with other ops or streams."""
+    key = _scratch_key(device)
     buf = _BN_SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.zeros(max(nbytes, 1 << 22), dtype=torch.uint8, device=device)
@@ -113,8 +120,16 @@ def set_profiler(p):
 
 
 def _size3(t):
-    v = [int(x) for x in (t.tolist() if hasattr(t, "tolist") else t)]
-    assert len(v) == 3, "only dimension 3 is built (Metadata_3)"
+    """Spatial size / filter / stride as a tuple of 3 ints.  LongTensors (the reference's representation) remember
+    their tuple: sizes are never modified in place, and a building asks for the same ones ~200 times."""
+    if type(t) is tuple and len(t) == 3:
+        return t
+    v = getattr(t, "_d3d_size3", None)
+    if v is None:
+        v = tuple(int(x) for x in (t.tolist() if hasattr(t, "tolist") else t))
+        assert len(v) == 3, "only dimension 3 is built (Metadata_3)"
+        if torch.is_tensor(t):
+            t._d3d_size3 = v
     return v
 
 
@@ -123,14 +138,18 @@ class Metadata_3(object):
     and rulebooks of one batch."""
 
     def __init__(self, arena_bytes=None):
+        # an arena is recycled only on the stream it was used on (stream order makes the reuse safe)
         self._dev = torch.cuda.current_device()
+        self._home = (self._dev, _lib.raw_stream(self._dev))
         key_bytes = arena_bytes or _ARENA_BYTES
-        for i, (dev, nbytes, h) in enumerate(_POOL):
-            if dev == self._dev and nbytes == key_bytes:
-                _POOL.pop(i)
-                self._h, self._bytes = h, nbytes
-                check(lib().d3d_meta_clear(self._h))
-                return
+        with _POOL_LOCK:
+            hit = next((e for e in _POOL if e[0] == self._home and e[1] == key_bytes), None)
+            if hit is not None:
+                _POOL.remove(hit)
+        if hit is not None:
+            self._h, self._bytes = hit[2], hit[1]
+            check(lib().d3d_meta_clear(self._h))
+            return
         h = ctypes.c_void_p()
         check(lib().d3d_meta_create(ctypes.byref(h), key_bytes))
         self._h, self._bytes = h, key_bytes
@@ -138,10 +157,11 @@ class Metadata_3(object):
     def __del__(self):
         h = getattr(self, "_h", None)
         if h is not None and _lib._lib is not None:
-            if len(_POOL) < 4:
-                _POOL.append((self._dev, self._bytes, h))
-            else:
-                _lib._lib.d3d_meta_destroy(h)
+            with _POOL_LOCK:
+                _POOL.append((self._home, self._bytes, h))
+                old = _POOL.pop(0) if len(_POOL) > 8 else None      # evict the oldest (its stream may be gone)
+            if old is not None:
+                _lib._lib.d3d_meta_destroy(old[2])
             self._h = None
 
     def clear(self):
@@ -311,6 +331,19 @@ def Convolution_prepare(input_size, output_size, filter_size, filter_stride, m):
     check(lib().d3d_conv_prepare(m._h, ints(isz), ints(osz), ints(filt), ints(st), stream_of(),
                                  ctypes.byref(n_out), None))
     return n_out.value
+
+
+def SubmanifoldConvolution_prepare(spatial_size, filter_size, m):
+    """Builds (or finds) the submanifold rulebook ahead of the convolutions that use it (Metadata::
+    getSubmanifoldRuleBook, Metadata.cpp:430-443); no host read-back."""
+    check(lib().d3d_subm_prepare(m._h, ints(_size3(spatial_size)), ints(_size3(filter_size)), stream_of(), None))
+
+
+def Deconvolution_prepare(input_size, output_size, filter_size, filter_stride, m):
+    """Builds (or finds) the deconvolution view (coarse `input_size` -> fine `output_size`) of the strided rulebook
+    that `Convolution_prepare(output_size, input_size, ...)` made; no host read-back."""
+    check(lib().d3d_deconv_prepare(m._h, ints(_size3(input_size)), ints(_size3(output_size)),
+                                   ints(_size3(filter_size)), ints(_size3(filter_stride)), stream_of(), None))
 
 
 def Convolution_updateOutput(input_size, output_size, filter_size, filter_stride, m, input_features,

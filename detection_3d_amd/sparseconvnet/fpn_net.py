@@ -110,21 +110,50 @@ class FPN_Net(torch.nn.Module):
                 i += 1
         return net
 
-    def prepare_geometry(self, net):
+    def prepare_geometry(self, net, full=False):
         """All strided grids / rulebooks of the pyramid, built before the first feature kernel: each new grid costs
         one host read-back of its site count, and here the stream holds only small geometry kernels when that
-        happens, so the feature pass that follows is enqueued without a single synchronisation."""
-        size = net.spatial_size
+        happens, so the feature pass that follows is enqueued without a single synchronisation.
+        full: also the submanifold 3x3x3 and deconvolution rulebooks (otherwise built by the first convolution that
+        needs them), which leaves the feature pass free of geometry kernels (serving.BuildingPipeline)."""
+        sizes = [net.spatial_size]
         for k in range(1, len(self.m_downs)):
             filt = scn.toLongTensor(self.dimension, self.down_kernels[k - 1])
             stride = scn.toLongTensor(self.dimension, self.down_strides[k - 1])
-            out = (size - filt) // stride + 1
-            scn.SCN.Convolution_prepare(size, out, filt, stride, net.metadata)
-            size = out
+            out = (sizes[-1] - filt) // stride + 1
+            scn.SCN.Convolution_prepare(sizes[-1], out, filt, stride, net.metadata)
+            sizes.append(out)
+        # the z-collapsing convolutions that project the selected RPN maps to 2-D make new grids too
+        n3d = len(self.fpn_scales_from_top)
+        for i in sorted({i - n3d for i in self.rpn_3d_2d_selector if i >= n3d} if self.skip_unused else range(n3d)):
+            size = sizes[len(sizes) - 1 - self.fpn_scales_from_top[i]]
+            conv = self.convs_pro2d[i]
+            scn.SCN.Convolution_prepare(size, (size - conv.filter_size) // conv.filter_stride + 1, conv.filter_size,
+                                        conv.filter_stride, net.metadata)
+        if full:
+            n_scales = len(self.m_downs)
+            for size in sizes:
+                scn.SCN.SubmanifoldConvolution_prepare(size, [3] * self.dimension, net.metadata)
+            needed = max(self.fpn_scales_from_top + self.roi_scales_from_top) if self.skip_unused else n_scales - 1
+            for k in range(min(n_scales - 1, needed)):
+                j = n_scales - 2 - k
+                scn.SCN.Deconvolution_prepare(sizes[j + 1], sizes[j], self.down_kernels[j], self.down_strides[j],
+                                              net.metadata)
 
-    def forward_fpn(self, net):
+    def stage_geometry(self, net0):
+        """Stage 1 of 3 of a pipelined pass (serving.BuildingPipeline): input layer + every grid and rulebook."""
+        net = self.layers_in[0](net0)
+        self.prepare_geometry(net, full=True)
+        return net
+
+    def stage_features(self, net):
+        """Stage 2: the feature pass over the prepared geometry (no host synchronisation)."""
+        return self.forward_fpn(self.layers_in[1](net), prepared=True)
+
+    def forward_fpn(self, net, prepared=False):
         n_scales = len(self.m_downs)
-        self.prepare_geometry(net)
+        if not prepared:
+            self.prepare_geometry(net)
         downs = []
         for m in self.m_downs:
             net = self._run_down(m, net)

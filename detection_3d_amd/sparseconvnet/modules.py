@@ -87,6 +87,22 @@ def _like(inp, features, spatial_size=None):
     return SparseConvNetTensor(features, inp.metadata, inp.spatial_size if spatial_size is None else spatial_size)
 
 
+class _NoGradCtx(object):
+    """Stand-in for the autograd context when gradients are off."""
+    needs_input_grad = ()
+
+    def save_for_backward(self, *tensors):
+        pass
+
+
+def _apply(fn, *args):
+    """fn.apply(*args); with gradients disabled the forward is called directly (autograd.Function.apply costs
+    ~10 us of Python per call, ~50 calls per building)."""
+    if torch.is_grad_enabled():
+        return fn.apply(*args)
+    return fn.forward(_NoGradCtx(), *args)
+
+
 class _InputLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, metadata, spatial_size, coords, batch_size, mode):
@@ -215,7 +231,7 @@ class InputLayer(Module):
     def forward(self, input):
         out = SparseConvNetTensor(metadata=Metadata(self.dimension), spatial_size=self.spatial_size)
         feats = input[1].to(self.device) if self.device else input[1]
-        out.features = _InputLayerFn.apply(feats, out.metadata, self.spatial_size, input[0],
+        out.features = _apply(_InputLayerFn, feats, out.metadata, self.spatial_size, input[0],
                                            0 if len(input) == 2 else input[2], self.mode)
         return out
 
@@ -235,7 +251,7 @@ class SubmanifoldConvolution(Module, _PackedWeightMixin):
     def forward(self, input, residual=None):
         feats, bn = _conv_input(input)
         assert feats.nelement() == 0 or feats.size(1) == self.nIn, (self.nIn, self.nOut)
-        f = _ConvFn.apply(feats, self.weight, None if residual is None else residual.features, 0,
+        f = _apply(_ConvFn, feats, self.weight, None if residual is None else residual.features, 0,
                           input.metadata, input.spatial_size, input.spatial_size, self.filter_size, None,
                           self._packed(), bn)
         return SparseConvNetTensor(f, input.metadata, input.spatial_size)
@@ -263,7 +279,7 @@ class Convolution(Module, _PackedWeightMixin):
         out_size = (input.spatial_size - self.filter_size) // self.filter_stride + 1
         assert ((out_size - 1) * self.filter_stride + self.filter_size == input.spatial_size).all(), \
             (input.spatial_size, out_size, self.filter_size, self.filter_stride)
-        f = _ConvFn.apply(feats, self.weight, None, 1, input.metadata, input.spatial_size, out_size,
+        f = _apply(_ConvFn, feats, self.weight, None, 1, input.metadata, input.spatial_size, out_size,
                           self.filter_size, self.filter_stride, self._packed(), bn)
         return SparseConvNetTensor(f, input.metadata, out_size)
 
@@ -288,7 +304,7 @@ class Deconvolution(Module, _PackedWeightMixin):
         feats, bn = _conv_input(input)
         assert feats.nelement() == 0 or feats.size(1) == self.nIn
         out_size = (input.spatial_size - 1) * self.filter_stride + self.filter_size
-        f = _ConvFn.apply(feats, self.weight, None if residual is None else residual.features, 2,
+        f = _apply(_ConvFn, feats, self.weight, None if residual is None else residual.features, 2,
                           input.metadata, input.spatial_size, out_size, self.filter_size, self.filter_stride,
                           self._packed(), bn)
         return SparseConvNetTensor(f, input.metadata, out_size)
@@ -325,7 +341,7 @@ class BatchNormalization(Module):
             mean, var = self.running_mean, self.running_var
         else:  # batchNormalization.py:53-55: batch statistics stand in for the running ones
             mean, var = SCN.batch_stats(f.detach())
-        y = _BatchNormFn.apply(f, self.weight if self.affine else None, self.bias if self.affine else None,
+        y = _apply(_BatchNormFn, f, self.weight if self.affine else None, self.bias if self.affine else None,
                                mean, var, self.eps, self.momentum, self.training, self.leakiness)
         return _like(input, y)
 
@@ -426,4 +442,4 @@ class SparseToDense(Module):
         if batch_size is None:
             loc = input.get_spatial_locations()
             batch_size = int(loc[:, 3].max().item()) + 1 if loc.shape[0] else 1
-        return _SparseToDenseFn.apply(input.features, input.metadata, input.spatial_size, self.nPlanes, batch_size)
+        return _apply(_SparseToDenseFn, input.features, input.metadata, input.spatial_size, self.nPlanes, batch_size)

@@ -111,3 +111,28 @@ def test_roi_pool_box_head_and_postprocess(setup, dev):
     assert np.array_equal(got["bbox3d"].cpu().numpy(), wb)
     assert np.allclose(got["scores"].cpu().numpy(), ws, atol=1e-6)
     assert got["bbox3d"].shape[0] <= cfg.MODEL.ROI_HEADS.DETECTIONS_PER_IMG + 5
+
+
+def test_buildings_in_flight_match_the_serial_loop_to_the_bit(setup, dev):
+    """serving.BuildingPipeline: 2 and 3 buildings in flight on their own streams give the serial loop's detections
+    to the bit (per-stream arenas / scratch, no shared state), for buildings of different sizes, and an empty list."""
+    from detection_3d_amd.serving import BuildingPipeline
+    from detection_3d_amd.synthetic import make_scene
+    from detection_3d_amd.voxelize import voxelize
+    cfg, model = setup[0], setup[1]
+    clouds = [torch.from_numpy(make_scene(10 + i, n)).to(dev) for i, n in enumerate((40000, 25000, 60000, 30000, 40000))]
+    serial = []
+    for pcl in clouds:
+        c, f = voxelize(pcl, cfg.SPARSE3D.VOXEL_SCALE, cfg.SPARSE3D.VOXEL_FULL_SCALE)
+        serial.append(model([c, f]))
+    assert sum(r["bbox3d"].shape[0] for r in serial) > 0
+    for n in (2, 3):
+        pipe = BuildingPipeline(model, cfg, in_flight=n, device=dev)
+        for rep in range(2):
+            got = pipe.map(clouds)
+            torch.cuda.synchronize()
+            assert len(got) == len(serial)
+            for g, r in zip(got, serial):
+                for k in ("bbox3d", "scores", "labels"):
+                    assert g[k].shape == r[k].shape and torch.equal(g[k], r[k]), (n, rep, k)
+        assert pipe.map([]) == []
