@@ -344,9 +344,9 @@ static int launch_t(d3d_meta *m, const Plan &p, const float *in, int cin, const 
   float *partial = nullptr;
   size_t mark = 0;
   if (n_split > 1) {
-    mark = m->arena.used;
-    partial = m->arena.get<float>((size_t)n_split * npos * COUT);
-    if (!partial) n_split = 1;  // arena full: fall back to the unsplit launch
+    mark = m->feat_arena.used;
+    partial = m->feat_arena.get<float>((size_t)n_split * npos * COUT);
+    if (!partial) n_split = 1;  // no room: fall back to the unsplit launch
   }
   const dim3 grid((p.n_blk + BPW - 1) / BPW, n_split);
   if (cin == CT * NCT)
@@ -359,7 +359,7 @@ static int launch_t(d3d_meta *m, const Plan &p, const float *in, int cin, const 
     const long total = (long)npos * (COUT / 4);
     hipLaunchKernelGGL(k_conv_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, partial, n_split,
                        npos, COUT / 4, p.rows, residual, out);
-    m->arena.used = mark;  // stream-ordered scratch
+    m->feat_arena.used = mark;  // stream-ordered scratch
   }
   D3D_LAUNCH_CHECK();
   return D3D_OK;

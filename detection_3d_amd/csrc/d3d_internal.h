@@ -125,7 +125,12 @@ struct StridedRaw {  // kept so that the deconvolution plan can be finalised laz
 }  // namespace d3d
 
 struct d3d_meta {
-  d3d::Arena arena;
+  d3d::Arena arena;       // first 2/3 of the slab: grids, rulebooks and the temporaries of building them
+  d3d::Arena feat_arena;  // last 1/3: temporaries of the feature pass (offset-split partial tiles, rule counts) and,
+                          // while a geometry stream is set, the rulebooks built on any other stream (grid.hip
+                          // lane_arena) -- each part is only ever used by one stream at a time
+  bool geo_locked = false;        // d3d_meta_set_geometry_stream: builds are only accepted on geo_stream
+  hipStream_t geo_stream = nullptr;
   std::map<d3d::Size3, d3d::Grid> grids;
   std::map<d3d::PlanKey, d3d::Plan> plans;
   std::map<d3d::PlanKey, d3d::StridedRaw> strided_raw;
@@ -151,6 +156,8 @@ int get_deconv_plan(d3d_meta *m, const int *fine_size, const int *filt, const in
                     hipStream_t s, const Plan **out);
 
 int grid_extent(d3d_meta *m, Grid &g, hipStream_t s);  // grid.hip: ensures g.extent
+int check_build_stream(d3d_meta *m, hipStream_t s, const char *what);
+Arena &lane_arena(d3d_meta *m, hipStream_t s);
 
 // conv.hip
 int launch_conv(d3d_meta *m, const Plan &p, const float *in, int cin, const float *packed_w, int cout,

@@ -455,7 +455,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_plan_small(const int32_t *__r
 int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan, hipStream_t s,
                   uint32_t *mask_in) {
   D3D_REQUIRE(K >= 1 && K <= 32, "filter volume %d not supported (1..32)", K);
-  Arena &A = m->arena;
+  Arena &A = lane_arena(m, s);
   plan.K = K;
   plan.n_rows = n_rows;
   plan.n_blk = (n_rows + 31) / 32;
@@ -498,10 +498,28 @@ int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan
   return D3D_OK;
 }
 
+// While a geometry stream is set (d3d_meta_set_geometry_stream) the slab has two single-stream lanes: the geometry
+// stream builds grids + strided rulebooks in `arena`, every other stream (the feature pass: submanifold / deconvolution
+// rulebooks built by the first convolution that needs them, partial tiles, rule counts) works in `feat_arena`, so
+// neither carves temporaries out of memory the other stream may still be using.
+Arena &lane_arena(d3d_meta *m, hipStream_t s) {
+  return (m->geo_locked && s != m->geo_stream) ? m->feat_arena : m->arena;
+}
+
+// New grids come from the geometry stream alone.
+int check_build_stream(d3d_meta *m, hipStream_t s, const char *what) {
+  if (m->geo_locked && s != m->geo_stream) {
+    set_error("%s requested on a stream other than the metadata's geometry stream (d3d_meta_set_geometry_stream): "
+              "prepare it there first", what);
+    return D3D_ERR_STATE;
+  }
+  return D3D_OK;
+}
+
 // reads the rule count back (one stream sync) the first time it is asked for
 int plan_rules(d3d_meta *m, Plan &p, hipStream_t s, long *out) {
   if (p.n_rules < 0) {
-    Arena &A = m->arena;
+    Arena &A = m->feat_arena;   // may run on the feature stream while geometry is built on another one
     size_t mark = A.used;
     D3D_ALLOC(cnt, unsigned long long, A, 1);
     D3D_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), s));
@@ -585,7 +603,7 @@ __global__ void k_grid_extent(const int32_t *__restrict__ loc, int n, int32_t *_
 }
 int grid_extent(d3d_meta *m, Grid &g, hipStream_t s) {
   if (g.extent) return D3D_OK;
-  D3D_ALLOC(e, int32_t, m->arena, 4);
+  D3D_ALLOC(e, int32_t, lane_arena(m, s), 4);
   D3D_HIP_CHECK(hipMemsetAsync(e, 0, 4 * sizeof(int32_t), s));
   if (g.n > 0) hipLaunchKernelGGL(k_grid_extent, grid1d(g.n), dim3(256), 0, s, g.loc, g.n, e);
   D3D_LAUNCH_CHECK();
@@ -733,7 +751,10 @@ int d3d_meta_create(d3d_meta **out, size_t arena_bytes) {
     delete m;
     return D3D_ERR_HIP;
   }
-  m->arena.cap = arena_bytes;
+  const size_t feat_bytes = (arena_bytes / 3) & ~size_t(255);   // second lane (see lane_arena)
+  m->arena.cap = arena_bytes - feat_bytes;
+  m->feat_arena.base = m->arena.base + m->arena.cap;
+  m->feat_arena.cap = feat_bytes;
   e = hipHostMalloc((void **)&m->host_words, 16 * sizeof(long), hipHostMallocDefault);
   if (e != hipSuccess) {
     set_error("hipHostMalloc failed: %s", hipGetErrorString(e));
@@ -754,11 +775,20 @@ int d3d_meta_destroy(d3d_meta *m) {
 int d3d_meta_clear(d3d_meta *m) {
   D3D_REQUIRE(m, "null metadata");
   m->arena.used = 0;
+  m->feat_arena.used = 0;
+  m->geo_locked = false;
+  m->geo_stream = nullptr;
   m->grids.clear();
   m->plans.clear();
   m->strided_raw.clear();
   m->in_n = m->in_mode = m->in_active = 0;
   m->in_off = m->in_idx = nullptr;
+  return D3D_OK;
+}
+int d3d_meta_set_geometry_stream(d3d_meta *m, void *stream, int enable) {
+  D3D_REQUIRE(m, "null metadata");
+  m->geo_locked = enable != 0;
+  m->geo_stream = enable ? (hipStream_t)stream : nullptr;
   return D3D_OK;
 }
 int d3d_meta_arena_used(d3d_meta *m, size_t *bytes_host) {
@@ -958,7 +988,7 @@ int d3d_subm_prepare(d3d_meta *m, const int *size, const int *filt, void *stream
     int K = filt[0] * filt[1] * filt[2];
     D3D_REQUIRE(filt[0] > 0 && filt[1] > 0 && filt[2] > 0 && K <= 32, "filter volume %d not supported", K);
     Plan p;
-    Arena &A = m->arena;
+    Arena &A = lane_arena(m, s);
     // raw table lives above the plan's persistent arrays: allocate persistent part first
     // (finalize_plan), so stage the raw table at the far end of the arena instead.
     size_t raw_bytes = ((size_t)g->n * K + 1) * sizeof(int32_t);
@@ -1009,6 +1039,7 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
   PlanKey key = make_key(1, in_size, filt, stride);
   auto it = m->plans.find(key);
   if (it == m->plans.end()) {
+    if (int rc = check_build_stream(m, s, "strided rulebook")) return rc;
     Grid *gi = find_grid(m, in_size);
     if (!gi) {
       set_error("strided rulebook: no grid of spatial size [%d,%d,%d]", in_size[0], in_size[1], in_size[2]);

@@ -15,7 +15,7 @@ import torch
 from .. import _lib
 from .._lib import check, ints, lib, ptr, require_gpu, stream_of
 
-_ARENA_BYTES = int(os.environ.get("D3D_ARENA_MB", "2048")) << 20
+_ARENA_BYTES = int(os.environ.get("D3D_ARENA_MB", "3072")) << 20   # 2/3 geometry lane + 1/3 feature lane
 _POOL = []          # recycled native metadata handles (one HBM arena each)
 _POOL_LOCK = threading.RLock()   # re-entrant: __del__ may run inside a locked region (GC)
 _SCRATCH = {}       # scratch tensors per (device, stream): buildings in flight on different streams never share one
@@ -166,6 +166,11 @@ class Metadata_3(object):
 
     def clear(self):
         check(lib().d3d_meta_clear(self._h))
+
+    def set_geometry_stream(self, raw_stream):
+        """d3d_meta_set_geometry_stream: rulebook / grid builds only on `raw_stream` (an int hipStream_t) from now
+        on; None lifts the restriction."""
+        check(lib().d3d_meta_set_geometry_stream(self._h, ctypes.c_void_p(raw_stream or 0), int(raw_stream is not None)))
 
     def getNActive(self, spatial_size):
         n = ctypes.c_int(0)

@@ -2,7 +2,7 @@
 SparseConvNet/sparseconvnet/fpn_net.py:12-137 (so `backbone.*` checkpoint keys load unchanged),
 same outputs as its forward_fpn (:168-265), executed by the HIP ops of libd3d_hip.so.
 
-Two execution switches that do not change any returned tensor:
+Execution switches that do not change any returned tensor (TWO_LANE below is a third):
   * fuse_adds     -- residual / lateral additions run in the epilogue of the producing
                      convolution instead of a separate AddTable / add_feature_planes pass;
   * skip_unused   -- the top-down levels whose outputs nothing consumes for the configured
@@ -14,6 +14,22 @@ import torch
 import torch.nn as nn
 
 from . import modules as scn
+
+TWO_LANE = True     # inference: geometry of the coarser levels on a side stream while the finer ones convolve
+_GEO_STREAMS = {}   # (device, caller's stream) -> high-priority side stream
+
+
+def _is_gpu_input(net0):
+    t = net0[1] if isinstance(net0, (list, tuple)) else getattr(net0, "features", None)
+    return torch.is_tensor(t) and t.is_cuda
+
+
+def _geometry_stream(main):
+    key = (main.device.index, main.cuda_stream)
+    st = _GEO_STREAMS.get(key)
+    if st is None:
+        st = _GEO_STREAMS[key] = torch.cuda.Stream(device=main.device, priority=-1)
+    return st
 
 
 class FPN_Net(torch.nn.Module):
@@ -88,8 +104,43 @@ class FPN_Net(torch.nn.Module):
 
     # ------------------------------------------------------------------------------------
     def forward(self, net0):
+        if TWO_LANE and not torch.is_grad_enabled() and _is_gpu_input(net0):
+            return self._forward_two_lane(net0)
         net1 = self.layers_in(net0)
         return self.forward_fpn(net1)
+
+    def _forward_two_lane(self, net0):
+        """Inference pass on two HIP streams: the chain of strided grids (small dependent kernels and one count
+        read-back per grid) is built on a high-priority side stream, level k+1 while the convolutions of level k --
+        and the submanifold / deconvolution rulebooks they build on first use -- run on the caller's stream, so the
+        read-backs no longer leave the GPU idle.  Same kernels on the same data as the one-stream pass
+        (bit-identical).  Meanwhile the metadata accepts new grids on the side stream only and gives each stream its
+        own part of the arena (d3d_meta_set_geometry_stream)."""
+        net = self.layers_in[0](net0)                       # input layer: grid of level 0
+        main = torch.cuda.current_stream(net.features.device)
+        geo = _geometry_stream(main)
+        md = net.metadata
+        geo.wait_stream(main)
+        md.set_geometry_stream(geo.cuda_stream)
+        steps, events = self._geometry_steps(net, False), []
+
+        def lane(k):        # level k is about to be enqueued: build its grid now (level k-1 is already in the queue)
+            while len(events) <= k:
+                with torch.cuda.stream(geo):
+                    next(steps)
+                    ev = torch.cuda.Event()
+                    ev.record(geo)
+                events.append(ev)
+            main.wait_event(events[k])
+
+        try:
+            lane(0)
+            net = self.layers_in[1](net)
+            out = self.forward_fpn(net, prepared=True, lane=lane)
+        finally:
+            main.wait_stream(geo)
+            md.set_geometry_stream(None)
+        return out
 
     def _run_down(self, m, net):
         if not (self.fuse_adds and self.residual_blocks):
@@ -110,35 +161,47 @@ class FPN_Net(torch.nn.Module):
                 i += 1
         return net
 
+    def _geometry_steps(self, net, full):
+        """Generator over the pyramid levels k = 0 .. n_scales-1: enqueues (on the current stream) everything level k
+        needs -- the strided grid + rulebook k-1 -> k (one host read-back of the site count), the z-collapsing RPN
+        projection grid of that level and, with `full`, the submanifold 3x3x3 / 1x1x1 rulebooks and the deconvolution
+        view k -> k-1 (otherwise built by the first convolution that needs them) -- then yields k."""
+        md, n_scales = net.metadata, len(self.m_downs)
+        needed = max(self.fpn_scales_from_top + self.roi_scales_from_top) if self.skip_unused else n_scales - 1
+        lowest_up = n_scales - 1 - min(n_scales - 1, needed)          # finest level the top-down path reaches
+        n3d = len(self.fpn_scales_from_top)
+        sel2d = sorted({i - n3d for i in self.rpn_3d_2d_selector if i >= n3d}) if self.skip_unused else range(n3d)
+        pro2d = {n_scales - 1 - self.fpn_scales_from_top[i]: self.convs_pro2d[i] for i in sel2d}
+        sizes = [net.spatial_size]
+        for k in range(n_scales):
+            if k > 0:
+                filt = scn.toLongTensor(self.dimension, self.down_kernels[k - 1])
+                stride = scn.toLongTensor(self.dimension, self.down_strides[k - 1])
+                out = (sizes[-1] - filt) // stride + 1
+                scn.SCN.Convolution_prepare(sizes[-1], out, filt, stride, md)
+                sizes.append(out)
+            size = sizes[k]
+            if k in pro2d:
+                conv = pro2d[k]
+                scn.SCN.Convolution_prepare(size, (size - conv.filter_size) // conv.filter_stride + 1,
+                                            conv.filter_size, conv.filter_stride, md)
+            if full:
+                scn.SCN.SubmanifoldConvolution_prepare(size, (3,) * self.dimension, md)
+                if k >= lowest_up:
+                    scn.SCN.SubmanifoldConvolution_prepare(size, (1,) * self.dimension, md)    # lateral 1x1x1
+                if k > lowest_up:
+                    scn.SCN.Deconvolution_prepare(size, sizes[k - 1], self.down_kernels[k - 1],
+                                                  self.down_strides[k - 1], md)
+            yield k
+
     def prepare_geometry(self, net, full=False):
         """All strided grids / rulebooks of the pyramid, built before the first feature kernel: each new grid costs
         one host read-back of its site count, and here the stream holds only small geometry kernels when that
         happens, so the feature pass that follows is enqueued without a single synchronisation.
-        full: also the submanifold 3x3x3 and deconvolution rulebooks (otherwise built by the first convolution that
-        needs them), which leaves the feature pass free of geometry kernels (serving.BuildingPipeline)."""
-        sizes = [net.spatial_size]
-        for k in range(1, len(self.m_downs)):
-            filt = scn.toLongTensor(self.dimension, self.down_kernels[k - 1])
-            stride = scn.toLongTensor(self.dimension, self.down_strides[k - 1])
-            out = (sizes[-1] - filt) // stride + 1
-            scn.SCN.Convolution_prepare(sizes[-1], out, filt, stride, net.metadata)
-            sizes.append(out)
-        # the z-collapsing convolutions that project the selected RPN maps to 2-D make new grids too
-        n3d = len(self.fpn_scales_from_top)
-        for i in sorted({i - n3d for i in self.rpn_3d_2d_selector if i >= n3d} if self.skip_unused else range(n3d)):
-            size = sizes[len(sizes) - 1 - self.fpn_scales_from_top[i]]
-            conv = self.convs_pro2d[i]
-            scn.SCN.Convolution_prepare(size, (size - conv.filter_size) // conv.filter_stride + 1, conv.filter_size,
-                                        conv.filter_stride, net.metadata)
-        if full:
-            n_scales = len(self.m_downs)
-            for size in sizes:
-                scn.SCN.SubmanifoldConvolution_prepare(size, [3] * self.dimension, net.metadata)
-            needed = max(self.fpn_scales_from_top + self.roi_scales_from_top) if self.skip_unused else n_scales - 1
-            for k in range(min(n_scales - 1, needed)):
-                j = n_scales - 2 - k
-                scn.SCN.Deconvolution_prepare(sizes[j + 1], sizes[j], self.down_kernels[j], self.down_strides[j],
-                                              net.metadata)
+        full: also the submanifold and deconvolution rulebooks, which leaves the feature pass free of geometry kernels
+        (serving.BuildingPipeline)."""
+        for _ in self._geometry_steps(net, full):
+            pass
 
     def stage_geometry(self, net0):
         """Stage 1 of 3 of a pipelined pass (serving.BuildingPipeline): input layer + every grid and rulebook."""
@@ -150,12 +213,14 @@ class FPN_Net(torch.nn.Module):
         """Stage 2: the feature pass over the prepared geometry (no host synchronisation)."""
         return self.forward_fpn(self.layers_in[1](net), prepared=True)
 
-    def forward_fpn(self, net, prepared=False):
+    def forward_fpn(self, net, prepared=False, lane=None):
         n_scales = len(self.m_downs)
         if not prepared:
             self.prepare_geometry(net)
         downs = []
-        for m in self.m_downs:
+        for k, m in enumerate(self.m_downs):
+            if lane is not None:
+                lane(k)
             net = self._run_down(m, net)
             downs.append(net)
         net = self.m_shortcuts[-1](net)

@@ -46,6 +46,14 @@ int d3d_meta_create(d3d_meta **out, size_t arena_bytes);
 int d3d_meta_destroy(d3d_meta *m);
 int d3d_meta_clear(d3d_meta *m);                       /* Metadata::clear, Metadata.cpp:30-45 */
 int d3d_meta_arena_used(d3d_meta *m, size_t *bytes_host);
+/* Two-lane building (no reference counterpart; the reference builds rulebooks on the CPU inside each layer's forward,
+ * Metadata.cpp:430-510).  enable != 0: new grids + strided rulebooks (d3d_conv_prepare) may only be BUILT on `stream`
+ * from now on (requested on another stream they fail with D3D_ERR_STATE instead of racing), and everything any other
+ * stream builds or stages (submanifold / deconvolution rulebooks, partial tiles) comes from a separate third of the
+ * slab -- so the caller may run the grid chain of the coarser levels, with its count read-backs, on `stream` while the
+ * convolutions of the finer levels run on another one.  The caller orders the two streams with events.  Reset by
+ * d3d_meta_clear.                                                                                                    */
+int d3d_meta_set_geometry_stream(d3d_meta *m, void *stream, int enable);
 
 /* a1. data3d/suncg_utils/suncg_dataset.py:97-177: a = xyz*scale in fp64, shift by per-axis min,
  * drop points outside [0, full_scale), trunc -> int64; feats[:,0:3] = a/scale.
