@@ -64,6 +64,20 @@ class ConvProfiler(object):
         self.macs = {}      # scene_key -> [macs of call 0, 1, ...]
         self._idx = 0
         self.records = []   # ((cin, cout) = one k_conv instantiation, flops, compulsory_bytes, start_event, end_event)
+        self._pool = []     # timing events created ahead of the timed region (reserve)
+
+    def reserve(self, n_events):
+        """Creates the HIP events of the next launches now: hipEventCreate inside the timed region costs host time
+        the two-lane pass has none to spare of."""
+        for _ in range(int(n_events)):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()         # torch creates the HIP event at its first record
+            self._pool.append(ev)
+
+    def _event(self):
+        ev = self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
+        ev.record()      # torch's current stream = the stream the kernels are launched on (stream_of)
+        return ev
 
     def start_scene(self, scene_key, learn):
         self.scene_key, self.learn, self._idx = scene_key, learn, 0
@@ -76,16 +90,13 @@ class ConvProfiler(object):
     def begin(self, kind=None, fv=None, cin=None, cout=None):
         if kind is not None and not self.wants(kind, fv, cin, cout):
             return None
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record(torch.cuda.current_stream())
-        return ev
+        return self._event()
 
     def end(self, start, kind, fv, cin, cout, rows_in, rows_out, macs):
         if start is None:       # not a focused family: only keep the call index aligned
             self._idx += 1
             return
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record(torch.cuda.current_stream())
+        ev = self._event()
         if self.learn:
             self.macs[self.scene_key].append(macs)
             return

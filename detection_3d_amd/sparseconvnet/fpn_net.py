@@ -25,10 +25,12 @@ def _is_gpu_input(net0):
 
 
 def _geometry_stream(main):
+    """-> (side stream, reusable per-level events) of the caller's stream"""
     key = (main.device.index, main.cuda_stream)
     st = _GEO_STREAMS.get(key)
     if st is None:
-        st = _GEO_STREAMS[key] = torch.cuda.Stream(device=main.device, priority=-1)
+        st = _GEO_STREAMS[key] = (torch.cuda.Stream(device=main.device, priority=-1),
+                                  [torch.cuda.Event() for _ in range(16)])
     return st
 
 
@@ -118,7 +120,7 @@ class FPN_Net(torch.nn.Module):
         own part of the arena (d3d_meta_set_geometry_stream)."""
         net = self.layers_in[0](net0)                       # input layer: grid of level 0
         main = torch.cuda.current_stream(net.features.device)
-        geo = _geometry_stream(main)
+        geo, pool = _geometry_stream(main)
         md = net.metadata
         geo.wait_stream(main)
         md.set_geometry_stream(geo.cuda_stream)
@@ -126,9 +128,9 @@ class FPN_Net(torch.nn.Module):
 
         def lane(k):        # level k is about to be enqueued: build its grid now (level k-1 is already in the queue)
             while len(events) <= k:
+                ev = pool[len(events)] if len(events) < len(pool) else torch.cuda.Event()
                 with torch.cuda.stream(geo):
                     next(steps)
-                    ev = torch.cuda.Event()
                     ev.record(geo)
                 events.append(ev)
             main.wait_event(events[k])
