@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from . import modules as scn
 
-TWO_LANE = True     # inference: geometry of the coarser levels on a side stream while the finer ones convolve
+TWO_LANE = True     # grid chain of the coarser levels on a side stream while the finer ones convolve
 _GEO_STREAMS = {}   # (device, caller's stream) -> high-priority side stream
 
 
@@ -106,13 +106,13 @@ class FPN_Net(torch.nn.Module):
 
     # ------------------------------------------------------------------------------------
     def forward(self, net0):
-        if TWO_LANE and not torch.is_grad_enabled() and _is_gpu_input(net0):
+        if TWO_LANE and _is_gpu_input(net0):
             return self._forward_two_lane(net0)
         net1 = self.layers_in(net0)
         return self.forward_fpn(net1)
 
     def _forward_two_lane(self, net0):
-        """Inference pass on two HIP streams: the chain of strided grids (small dependent kernels and one count
+        """Forward pass on two HIP streams: the chain of strided grids (small dependent kernels and one count
         read-back per grid) is built on a high-priority side stream, level k+1 while the convolutions of level k --
         and the submanifold / deconvolution rulebooks they build on first use -- run on the caller's stream, so the
         read-backs no longer leave the GPU idle.  Same kernels on the same data as the one-stream pass

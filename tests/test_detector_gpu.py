@@ -136,3 +136,43 @@ def test_buildings_in_flight_match_the_serial_loop_to_the_bit(setup, dev):
                 for k in ("bbox3d", "scores", "labels"):
                     assert g[k].shape == r[k].shape and torch.equal(g[k], r[k]), (n, rep, k)
         assert pipe.map([]) == []
+
+
+def test_two_lane_pass_matches_the_one_stream_pass_to_the_bit(setup, dev):
+    """FPN_Net._forward_two_lane (grid chain on a side stream, per-stream arena lanes) vs the one-stream pass: every
+    backbone map and the detections are identical to the bit; a grid requested on the wrong stream is refused."""
+    from detection_3d_amd import _lib
+    from detection_3d_amd.sparseconvnet import SCN, fpn_net
+    from detection_3d_amd.synthetic import make_scene
+    from detection_3d_amd.voxelize import voxelize
+    cfg, model = setup[0], setup[1]
+    pcl = torch.from_numpy(make_scene(21, 50000)).to(dev)
+    outs = {}
+    try:
+        for two in (False, True, True):
+            fpn_net.TWO_LANE = two
+            c, f = voxelize(pcl, cfg.SPARSE3D.VOXEL_SCALE, cfg.SPARSE3D.VOXEL_FULL_SCALE)
+            res, mid = model([c, f], return_intermediates=True)
+            torch.cuda.synchronize()
+            got = [m.features.clone() for m in mid["rpn_features"] + mid["roi_features"]] + \
+                  [res["bbox3d"], res["scores"], res["labels"], mid["proposals"]]
+            if two in outs:
+                assert all(torch.equal(a, b) for a, b in zip(outs[two], got))
+            outs[two] = got
+    finally:
+        fpn_net.TWO_LANE = True
+    assert len(outs[False]) == len(outs[True])
+    for a, b in zip(outs[False], outs[True]):
+        assert a.shape == b.shape and torch.equal(a, b)
+    # the guard: with a geometry stream set, a new grid on another stream is an error, not a race
+    c, f = voxelize(pcl, cfg.SPARSE3D.VOXEL_SCALE, cfg.SPARSE3D.VOXEL_FULL_SCALE)
+    net = model.backbone.layers_in[0]([c, f])
+    side = torch.cuda.Stream(device=dev)
+    net.metadata.set_geometry_stream(side.cuda_stream)
+    size = net.spatial_size
+    with pytest.raises(_lib.D3DError, match="geometry stream"):
+        SCN.Convolution_prepare(size, (size - 2) // 2 + 1, [2, 2, 2], [2, 2, 2], net.metadata)
+    with torch.cuda.stream(side):
+        assert SCN.Convolution_prepare(size, (size - 2) // 2 + 1, [2, 2, 2], [2, 2, 2], net.metadata) > 0
+    net.metadata.set_geometry_stream(None)
+    torch.cuda.synchronize()
