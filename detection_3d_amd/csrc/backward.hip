@@ -36,6 +36,7 @@ __global__ void k_pack_weight_t(const float *__restrict__ w, int fv, int cin, in
 
 static constexpr int kDwBlocksPerWg = 64;
 static constexpr int kDwTargetWgs = 1024;
+static constexpr int kDwMaxChunk = 8;
 
 // One workgroup: offset k = blockIdx.y, a run of kDwBlocksPerWg row blocks, a group of <= 16 output tiles (32x32).
 // The blocks of the run that have offset k are found with one ballot; their operands (32 gathered input rows and
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ in, i
                                                  const int32_t *__restrict__ nbrT, int npos,
                                                  const int32_t *__restrict__ rows,
                                                  const uint32_t *__restrict__ blkmask, int n_blk, int run,
-                                                 float *__restrict__ dW) {
+                                                 int chunk, int nz_tiles, float *__restrict__ dW) {
   constexpr int NTI = CP / 32, NTJ = COUT / 32, T = NTI * NTJ;
   constexpr int TPG = T < 16 ? T : 16;             // tiles per group (grid.z)
   constexpr int TPW = (TPG + 3) / 4;               // tiles per wave
@@ -64,7 +65,21 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ in, i
   // blocks of this run (<= 64) that have a rule at offset k
   const uint32_t mymask = (lane < run && b0 + lane < n_blk) ? blkmask[b0 + lane] : 0u;
   unsigned long long active = __ballot((mymask >> k) & 1u);
+  // The run's active blocks are dealt out in chunks of `chunk` to the workgroups blockIdx.z / nz_tiles = 0, 1, ...:
+  // a dense offset (the centre one is present in every block) no longer makes one workgroup walk the whole run
+  // while the workgroups of the sparse offsets have long finished.
+  {
+    const int c = blockIdx.z / nz_tiles;
+    for (int d = 0; d < c * chunk && active; d++) active &= active - 1;
+    unsigned long long keep = 0, rest = active;
+    for (int d = 0; d < chunk && rest; d++) {
+      keep |= rest & (~rest + 1);
+      rest &= rest - 1;
+    }
+    active = keep;
+  }
   if (!active) return;
+  const int zt = blockIdx.z % nz_tiles;   // tile group
   f32x16 acc[TPW];
 #pragma unroll
   for (int t = 0; t < TPW; t++)
@@ -151,7 +166,7 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ in, i
     }
 #pragma unroll
     for (int t = 0; t < TPW; t++) {
-      const int tile = blockIdx.z * TPG + wave * TPW + t;
+      const int tile = zt * TPG + wave * TPW + t;
       if (wave * TPW + t >= TPG || tile >= T) continue;
       const int ti = tile / NTJ, tj = tile % NTJ;
 #pragma unroll
@@ -167,7 +182,7 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ in, i
   }
 #pragma unroll
   for (int t = 0; t < TPW; t++) {
-    const int tile = blockIdx.z * TPG + wave * TPW + t;
+    const int tile = zt * TPG + wave * TPW + t;
     if (wave * TPW + t >= TPG || tile >= T) continue;
     const int ti = tile / NTJ, tj = tile % NTJ;
 #pragma unroll
@@ -184,13 +199,24 @@ static int launch_dw_t(const Plan &p, const float *in, int cin, const float *d_o
   constexpr int T = (CP / 32) * (COUT / 32);
   constexpr int TPG = T < 16 ? T : 16;
   // run length: long runs amortise the final atomics of a workgroup (T * 1024 of them), short runs keep a small
-  // plan from being walked serially by a handful of workgroups -- aim at >= kDwTargetWgs workgroups
+  // plan from being walked serially by a handful of workgroups -- aim at >= kDwTargetWgs workgroups.  Plans so large
+  // that the run hits the 64 blocks one ballot covers deal the run's active blocks out in chunks of kDwMaxChunk
+  // instead: the dense offsets (the centre one is in every block) would otherwise set the kernel's duration
+  // (measured: Cin = Cout = 64 at 370 k rows 236 -> 186 us, 32 at 460 k rows 124 -> 90 us; smaller plans lose).
   const int nz = (T + TPG - 1) / TPG;
   long run = ((long)p.n_blk * p.K * nz + kDwTargetWgs - 1) / kDwTargetWgs;
-  run = std::max<long>(2, std::min<long>(kDwBlocksPerWg, run));
-  dim3 grid((unsigned)((p.n_blk + run - 1) / run), p.K, nz);
+  long chunk;
+  if (run >= kDwBlocksPerWg) {
+    run = kDwBlocksPerWg;
+    chunk = kDwMaxChunk;
+  } else {
+    run = std::max<long>(2, run);
+    chunk = run;
+  }
+  const int n_chunks = (int)((run + chunk - 1) / chunk);
+  dim3 grid((unsigned)((p.n_blk + run - 1) / run), p.K, nz * n_chunks);
   hipLaunchKernelGGL((k_conv_dw<CP, COUT>), grid, dim3(256), 0, s, in, cin, d_out, p.nbrT, p.n_blk * 32, p.rows,
-                     p.blkmask, p.n_blk, (int)run, dW);
+                     p.blkmask, p.n_blk, (int)run, (int)chunk, nz, dW);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }
