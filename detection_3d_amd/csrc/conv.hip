@@ -330,6 +330,9 @@ __global__ __launch_bounds__(256) void k_conv_reduce(const float *__restrict__ p
 
 static constexpr int kSplitTargetWaves = 2048;  // below this many waves the launch is offset-split
 
+// d3d_conv_time_next: HIP events the next k_conv launch of this thread is bracketed with (measurement only)
+static thread_local hipEvent_t t_time_start = nullptr, t_time_stop = nullptr;
+
 template <int CT, int NCT, int COUT, int NT, int BPW>
 static int launch_t(d3d_meta *m, const Plan &p, const float *in, int cin, const float *wp,
                     const float *residual, float *out, hipStream_t s, BnPre pre) {
@@ -349,12 +352,16 @@ static int launch_t(d3d_meta *m, const Plan &p, const float *in, int cin, const 
     if (!partial) n_split = 1;  // no room: fall back to the unsplit launch
   }
   const dim3 grid((p.n_blk + BPW - 1) / BPW, n_split);
+  const hipEvent_t ev_start = t_time_start, ev_stop = t_time_stop;
+  t_time_start = t_time_stop = nullptr;
+  if (ev_start) (void)hipEventRecord(ev_start, s);
   if (cin == CT * NCT)
     hipLaunchKernelGGL((k_conv<CT, NCT, COUT, NT, BPW, true>), grid, dim3(threads), 0, s, in, cin, wp, p.nbrT, npos,
                        p.rows, p.blkmask, p.n_blk, residual, out, n_split, partial, pre);
   else
     hipLaunchKernelGGL((k_conv<CT, NCT, COUT, NT, BPW, false>), grid, dim3(threads), 0, s, in, cin, wp, p.nbrT, npos,
                        p.rows, p.blkmask, p.n_blk, residual, out, n_split, partial, pre);
+  if (ev_stop) (void)hipEventRecord(ev_stop, s);   // k_conv alone: the reduction of an offset-split launch follows
   if (n_split > 1) {
     const long total = (long)npos * (COUT / 4);
     hipLaunchKernelGGL(k_conv_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, partial, n_split,
@@ -382,7 +389,12 @@ static int launch_c(d3d_meta *m, const Plan &p, const float *in, int cin, const 
 
 int launch_conv(d3d_meta *m, const Plan &p, const float *in, int cin, const float *packed_w, int cout,
                 const float *residual, float *out, hipStream_t s, const d3d_bn_prologue *bn) {
-  if (p.n_rows == 0) return D3D_OK;
+  if (p.n_rows == 0) {
+    if (t_time_start) (void)hipEventRecord(t_time_start, s);
+    if (t_time_stop) (void)hipEventRecord(t_time_stop, s);
+    t_time_start = t_time_stop = nullptr;
+    return D3D_OK;
+  }
   D3D_REQUIRE(in && packed_w && out, "convolution: null pointer");
   D3D_REQUIRE((size_t)p.n_in * (size_t)cin * 4 < ((size_t)1 << 32),
               "convolution: gathered tensor of %d rows x %d channels exceeds the 4 GiB of the 32-bit gather offsets", p.n_in, cin);
@@ -407,6 +419,12 @@ int launch_conv(d3d_meta *m, const Plan &p, const float *in, int cin, const floa
 using namespace d3d;
 
 extern "C" {
+
+int d3d_conv_time_next(void *start_event, void *stop_event) {
+  t_time_start = (hipEvent_t)start_event;
+  t_time_stop = (hipEvent_t)stop_event;
+  return D3D_OK;
+}
 
 size_t d3d_packed_weight_floats(int fv, int cin, int cout) {
   int cp = padded_cin(cin);

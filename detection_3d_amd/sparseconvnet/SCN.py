@@ -75,8 +75,10 @@ class ConvProfiler(object):
             self._pool.append(ev)
 
     def _event(self):
-        ev = self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
-        ev.record()      # torch's current stream = the stream the kernels are launched on (stream_of)
+        if self._pool:
+            return self._pool.pop()
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()             # creates the HIP event (torch does it at the first record)
         return ev
 
     def start_scene(self, scene_key, learn):
@@ -88,15 +90,18 @@ class ConvProfiler(object):
         return self.learn or self.focus is None or (cin, cout) in self.focus
 
     def begin(self, kind=None, fv=None, cin=None, cout=None):
+        """Arms the library to bracket the k_conv launch of the convolution call that follows with two HIP events
+        (d3d_conv_time_next) -> (start, stop), or None if this convolution family is not being timed."""
         if kind is not None and not self.wants(kind, fv, cin, cout):
             return None
-        return self._event()
+        pair = (self._event(), self._event())
+        check(lib().d3d_conv_time_next(ctypes.c_void_p(pair[0].cuda_event), ctypes.c_void_p(pair[1].cuda_event)))
+        return pair
 
     def end(self, start, kind, fv, cin, cout, rows_in, rows_out, macs):
         if start is None:       # not a focused family: only keep the call index aligned
             self._idx += 1
             return
-        ev = self._event()
         if self.learn:
             self.macs[self.scene_key].append(macs)
             return
@@ -105,7 +110,7 @@ class ConvProfiler(object):
         rules = macs / max(cin * cout, 1)
         # FLOPs = 2*rules*Cin*Cout; compulsory bytes = 4*(rows_in*Cin + rows_out*Cout) + 8*rules
         self.records.append(((cin, cout), 2.0 * macs, 4.0 * (rows_in * cin + rows_out * cout) + 8.0 * rules,
-                             start, ev))
+                             start[0], start[1]))
 
     def summary(self):
         """{key: dict(calls, ms, flops, bytes)}; call after torch.cuda.synchronize()."""

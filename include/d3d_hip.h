@@ -108,6 +108,11 @@ int d3d_export_rules(d3d_meta *m, int kind, const int *in_size_host, const int *
                      const int *stride_host, int32_t *triples, long capacity, long *n_host,
                      void *stream);
 
+/* Measurement hook (bench.py's roofline leg; no reference counterpart): the next sparse-convolution launch made by
+ * the calling thread records the two HIP events (hipEvent_t, created with timing) on its stream immediately before
+ * and after the k_conv kernel itself -- not the k_conv_reduce of an offset-split launch -- so that the live average
+ * is the duration `rocprofv3 --kernel-trace --stats` reports for that kernel name.  NULLs disarm.                */
+int d3d_conv_time_next(void *start_event, void *stop_event);
 /* Conv weights: reference layout [filter_volume, groups=1, Cin, Cout]
  * (sparseconvnet/submanifoldConvolution.py:24-26).  The kernels read a k-interleaved copy
  * [fv][ceil(Cin/8)*2][Cout][4]; pack once per weight update.                                 */
