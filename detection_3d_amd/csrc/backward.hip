@@ -361,6 +361,50 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply4(const float *__restrict__
   }
   *(f32x4 *)(dx + i) = o;
 }
+// the same arithmetic with one 4-channel group per thread walking rows (parameters read once per thread, see
+// k_bn_apply_rows in bn.hip); C4 = C / 4 divides 256
+__global__ __launch_bounds__(256) void k_bn_bwd_apply_rows(const float *__restrict__ x, const float *__restrict__ y,
+                                                           const float *__restrict__ dy, float *__restrict__ dx,
+                                                           int rows, int C, const float *__restrict__ mean,
+                                                           const float *__restrict__ invstd,
+                                                           const float *__restrict__ weight,
+                                                           const float *__restrict__ grad_mean,
+                                                           const float *__restrict__ kcoef, float leak) {
+  const int C4 = C >> 2, RPI = 256 / C4;
+  const int cg = threadIdx.x % C4, rl = threadIdx.x / C4;
+  const int c = cg * 4;
+  f32x4 gm, mu, kc, is, wt;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    gm[j] = grad_mean[c + j];
+    mu[j] = mean[c + j];
+    kc[j] = kcoef[c + j];
+    is[j] = invstd[c + j];
+    wt[j] = weight ? weight[c + j] : 1.f;
+  }
+  const size_t step = (size_t)gridDim.x * RPI;
+  auto one = [&](f32x4 vx, f32x4 vy, f32x4 vd) {
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float d = vd[j] * ((vy[j] > 0) ? 1.f : leak);
+      o[j] = (d - gm[j] - (vx[j] - mu[j]) * kc[j]) * is[j] * wt[j];
+    }
+    return o;
+  };
+  size_t r = (size_t)blockIdx.x * RPI + rl;
+  for (; r + step < (size_t)rows; r += 2 * step) {   // 2 rows = 6 loads in flight
+    const size_t i0 = r * C + c, i1 = (r + step) * C + c;
+    const f32x4 x0 = *(const f32x4 *)(x + i0), y0 = *(const f32x4 *)(y + i0), d0 = *(const f32x4 *)(dy + i0);
+    const f32x4 x1 = *(const f32x4 *)(x + i1), y1 = *(const f32x4 *)(y + i1), d1 = *(const f32x4 *)(dy + i1);
+    *(f32x4 *)(dx + i0) = one(x0, y0, d0);
+    *(f32x4 *)(dx + i1) = one(x1, y1, d1);
+  }
+  for (; r < (size_t)rows; r += step) {
+    const size_t i0 = r * C + c;
+    *(f32x4 *)(dx + i0) = one(*(const f32x4 *)(x + i0), *(const f32x4 *)(y + i0), *(const f32x4 *)(dy + i0));
+  }
+}
 __global__ __launch_bounds__(256) void k_bn_bwd_finish(const double *__restrict__ partial, int nblk, int rows,
                                                        int C, const float *__restrict__ invstd,
                                                        float *grad_mean, float *kcoef, float *d_weight,
@@ -527,7 +571,13 @@ int d3d_bn_backward(const float *in, const float *out, const float *d_out, float
   hipLaunchKernelGGL(k_bn_bwd_finish, dim3((planes + 31) / 32), dim3(256), 0, s, partial, nblk, rows, planes,
                      save_invstd, grad_mean, kcoef, d_weight, d_bias);
   size_t total = (size_t)rows * planes;
-  if (vec4)
+  if (vec4 && planes / 4 <= 256 && 256 % (planes / 4) == 0) {
+    const int rpi = 256 / (planes / 4);
+    const long need = ((long)rows + rpi - 1) / rpi;
+    const unsigned blocks = (unsigned)std::max<long>(1, std::min<long>(need, 256 * 8));
+    hipLaunchKernelGGL(k_bn_bwd_apply_rows, dim3(blocks), dim3(256), 0, s, in, out, d_out, d_in, rows, planes, save_mean,
+                       save_invstd, weight, grad_mean, kcoef, leakiness);
+  } else if (vec4)
     hipLaunchKernelGGL(k_bn_bwd_apply4, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, in, out, d_out, d_in,
                        total / 4, planes, save_mean, save_invstd, weight, grad_mean, kcoef, leakiness);
   else
