@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libd3d_hip.so")
 _lib = None
 
 c_int_p = ctypes.POINTER(ctypes.c_int)
+c_float_p = ctypes.POINTER(ctypes.c_float)
 vp = ctypes.c_void_p
 
 
@@ -30,6 +31,8 @@ _SIGS = {
     "d3d_meta_arena_used": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_size_t)]),
     "d3d_meta_set_geometry_stream": (ctypes.c_int, [vp, vp, ctypes.c_int]),
     "d3d_conv_time_next": (ctypes.c_int, [vp, vp]),
+    "d3d_roi_prepare": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_float, c_float_p, ctypes.c_int, ctypes.c_float, vp, vp,
+                                       vp]),
     "d3d_voxelize": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_int_p, vp, vp,
                                     c_int_p, vp, ctypes.c_size_t, vp]),
     "d3d_voxelize_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int]),

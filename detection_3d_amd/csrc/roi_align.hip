@@ -355,7 +355,67 @@ __global__ __launch_bounds__(256) void k_roi_sparse_bwd(
 
 using namespace d3d;
 
+// Pooler pre-processing in one launch (what the reference spreads over ~25 tensor ops): metric yx_zb proposals ->
+// the op's RoI rows (batch 0, centre x, centre y, centre z, size x, size y, size z, yaw in degrees, in pixels of the
+// full-resolution grid) and the FPN level of every RoI.  The arithmetic is the reference's, operation by operation in
+// fp32 (a division by a constant is the product with its fp32 reciprocal, as the tensor library evaluates it), so
+// that the result equals the host-side chain bit for bit (tests/test_boxes_gpu.py).
+struct RoiPrepScales {
+  float v[8];
+};
+__global__ __launch_bounds__(256) void k_roi_prepare(const float *__restrict__ boxes, int n, float voxel_scale,
+                                                     RoiPrepScales scales, int n_levels, float inv_canonical,
+                                                     float *__restrict__ rois, int32_t *__restrict__ levels) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float b[7];
+#pragma unroll
+  for (int j = 0; j < 7; j++) b[j] = boxes[(size_t)i * 7 + j];
+#pragma unroll
+  for (int j = 0; j < 6; j++) b[j] *= voxel_scale;                  // convert_metric_to_pixel
+  const float kHalfPi = (float)(3.14159265358979323846 * 0.5), kPi = (float)3.14159265358979323846;
+  const float kInvPi = 1.f / kPi, kDeg = (float)(180.0 / 3.14159265358979323846);
+  float yaw = b[6] + kHalfPi;                                        // yx_zb -> standard (bounding_box_3d.py:221-242)
+  yaw = yaw - floorf(yaw * kInvPi + 0.f) * kPi;                      // limit_period(yaw, 0, pi)
+  float *r = rois + (size_t)i * 8;
+  r[0] = 0.f;
+  r[1] = b[1];
+  r[2] = b[0];
+  r[3] = b[2] + b[5] * 0.5f;
+  r[4] = b[3];
+  r[5] = b[4];
+  r[6] = b[5];
+  r[7] = yaw * kDeg;
+  if (levels) {                                                      // poolers_3d.py LevelMapper
+    const float rate = sqrtf(fmaxf(b[3], b[4])) * inv_canonical;
+    int best = 0;
+    float bd = fabsf(scales.v[0] - rate);
+    for (int l = 1; l < n_levels; l++) {
+      const float d = fabsf(scales.v[l] - rate);
+      if (d < bd) {
+        bd = d;
+        best = l;
+      }
+    }
+    levels[i] = best;
+  }
+}
+
 extern "C" {
+
+int d3d_roi_prepare(const float *boxes_metric, int n, float voxel_scale, const float *scales_host, int n_levels,
+                    float canonical_size, float *rois, int32_t *levels, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(n >= 0 && n_levels >= 0 && n_levels <= 8, "roi_prepare: bad arguments (at most 8 levels)");
+  if (n == 0) return D3D_OK;
+  D3D_REQUIRE(boxes_metric && rois && (n_levels == 0 || scales_host), "roi_prepare: null pointer");
+  RoiPrepScales sc = {};
+  for (int l = 0; l < n_levels; l++) sc.v[l] = scales_host[l];
+  hipLaunchKernelGGL(k_roi_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, boxes_metric, n, voxel_scale, sc,
+                     n_levels, 1.f / canonical_size, rois, n_levels > 1 ? levels : nullptr);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
 
 int d3d_roi_align_rotated_3d_forward(const float *input, int B, int C, int H, int W, int Z,
                                      const float *rois, int K, float spatial_scale, int ph, int pw,

@@ -23,7 +23,7 @@ from . import box_ops
 from . import sparseconvnet as scn
 from . import training as T
 from .config import class_to_label
-from .roi_align_rotated_3d import roi_align_rotated_3d_sparse, roi_align_rotated_3d_sparse_into
+from .roi_align_rotated_3d import roi_align_rotated_3d_sparse, roi_align_rotated_3d_sparse_into, roi_prepare
 from .sparseconvnet import SCN
 
 
@@ -264,6 +264,20 @@ class Pooler(nn.Module):
         dif = torch.abs(torch.tensor(self.scales, device=boxes.device)[None, :] - rate[:, None])
         return torch.argmin(dif, 1)
 
+    def pool_metric(self, x, boxes_metric, voxel_scale, channels_inner=True):
+        """Inference: metric proposals -> pooled features with ONE pre-processing launch (pixels, RoI format and FPN
+        level: d3d_roi_prepare, bit-identical to convert_to_roi_format / map_levels) and one launch per level that
+        fills its RoIs' slots of the result in place (no nonzero / index_put, no host synchronisation)."""
+        ph, pw, pz = self.output_size
+        rois, levels = roi_prepare(boxes_metric, voxel_scale, self.scales, self.canonical_size)
+        K, C = rois.shape[0], x[0].features.shape[1]
+        out = torch.empty((K, ph, pw, C, pz) if channels_inner else (K, C, ph, pw, pz), dtype=torch.float32,
+                          device=rois.device)
+        for level, (fmap, scale) in enumerate(zip(x, self.scales)):       # crop = occupied extent, found on the device
+            roi_align_rotated_3d_sparse_into(out, fmap, rois, scale, self.sampling_ratio, crop=None,
+                                             roi_levels=levels, level=level, channels_inner=channels_inner)
+        return out
+
     def forward(self, x, boxes_pixels, channels_inner=False):
         """-> [K, C, ph, pw, pz]; channels_inner (inference only): [K, ph, pw, C, pz]."""
         with torch.no_grad():
@@ -336,11 +350,11 @@ class FPN2MLPFeatureExtractor(nn.Module):
         return self._fc6_rows[1]
 
     def _forward_rows(self, x0, p):
-        """Inference path without layout changes: the pooler writes [K, ph, pw, C, pz], whose rows feed the
+        """Inference path without layout changes (p: metric proposals): the pooler writes [K, ph, pw, C, pz], whose rows feed the
         [1,1,pz] convolution as a GEMM; BatchNorm3d + ReLU is one row-wise BatchNorm over [K*ph*pw, rep]
         (batch statistics, biased variance: F.batch_norm in training mode), fc6 reads the rows in place."""
         conv, bn = self.conv3d[0], self.conv3d[1]
-        pooled = self.pooler(x0, p, channels_inner=True)
+        pooled = self.pooler.pool_metric(x0, p, self.voxel_scale, channels_inner=True)
         K, ph, pw, C, pz = pooled.shape
         y = torch.addmm(conv.bias, pooled.view(K * ph * pw, C * pz), conv.weight.view(conv.out_channels, C * pz).t())
         rep = y.shape[1]
@@ -351,13 +365,13 @@ class FPN2MLPFeatureExtractor(nn.Module):
         return F.relu(self.fc7(F.relu(h)))
 
     def forward(self, x0, proposals):
-        p = proposals.clone()
-        p[:, 0:6] *= self.voxel_scale                                           # convert_metric_to_pixel
         conv, bn = self.conv3d[0], self.conv3d[1]
         if (not torch.is_grad_enabled() and tuple(conv.kernel_size) == (1, 1, self.pooler.output_size[2])
                 and tuple(conv.stride) == (1, 1, 1) and (bn.training or not bn.track_running_stats)
                 and proposals.shape[0] > 0):
-            return self._forward_rows(x0, p)
+            return self._forward_rows(x0, proposals)                            # metric boxes: pixels on the device
+        p = proposals.clone()
+        p[:, 0:6] *= self.voxel_scale                                           # convert_metric_to_pixel
         x1 = self._head_conv(self.pooler(x0, p))
         x2 = x1.reshape(x1.size(0), -1)
         return F.relu(self.fc7(F.relu(self.fc6(x2))))

@@ -3,7 +3,7 @@
 SparseConvNetTensor through its hash grid (no dense [1,128,256,256,32] = 1.07 GB map)."""
 import torch
 
-from ._lib import check, ints, lib, ptr, require_gpu, stream_of
+from ._lib import check, floats, ints, lib, ptr, require_gpu, stream_of
 
 
 def roi_align_rotated_3d_backward(grad, rois, spatial_scale, pooled_height, pooled_width, pooled_zsize,
@@ -115,6 +115,19 @@ def roi_align_rotated_3d_sparse_into(out, feat_s3d, rois, spatial_scale, samplin
         r.shape[0], float(spatial_scale), ph, pw, pz, int(sampling_ratio), ptr(roi_levels), int(level),
         1 if channels_inner else 0, ptr(out), stream_of()))
     return out
+
+
+def roi_prepare(boxes_metric, voxel_scale, scales, canonical_size):
+    """d3d_roi_prepare: metric yx_zb proposals [K,7] -> (rois [K,8] in pixels, levels int32 [K] or None for a single
+    level) in one launch; equals convert_metric_to_pixel + convert_to_roi_format + Pooler.map_levels bit for bit."""
+    b = boxes_metric.detach().to(torch.float32).contiguous()
+    require_gpu(b)
+    K = b.shape[0]
+    rois = torch.empty((K, 8), dtype=torch.float32, device=b.device)
+    levels = torch.empty((K,), dtype=torch.int32, device=b.device) if len(scales) > 1 else None
+    check(lib().d3d_roi_prepare(ptr(b), K, float(voxel_scale), floats(scales), len(scales), float(canonical_size),
+                                ptr(rois), ptr(levels), stream_of()))
+    return rois, levels
 
 
 class ROIAlignRotated3D(torch.nn.Module):

@@ -223,3 +223,31 @@ def test_nms_batched_segments_match_single_lists(dev):
         assert nk[k] == len(want)
         assert np.array_equal(keep[k, :nk[k]], want)
     assert nk[0] < counts[0]
+
+
+def test_roi_prepare_equals_the_host_side_chain_bit_for_bit(dev):
+    """d3d_roi_prepare (pixels + RoI format + FPN level in one launch) vs convert_metric_to_pixel ->
+    convert_to_roi_format -> Pooler.map_levels, the tensor-op mirror of poolers_3d.py: identical bits, 1 and 3 levels."""
+    from detection_3d_amd.detector import Pooler, convert_to_roi_format
+    from detection_3d_amd.roi_align_rotated_3d import roi_prepare
+    g = torch.Generator().manual_seed(5)
+    n = 5000
+    b = torch.zeros(n, 7)
+    b[:, 0:3] = torch.rand(n, 3, generator=g) * torch.tensor([20.0, 25.0, 3.0])
+    b[:, 3:6] = torch.rand(n, 3, generator=g) * torch.tensor([8.0, 0.6, 2.9]) + 0.001
+    b[:, 6] = (torch.rand(n, generator=g) - 0.5) * 7.0                 # beyond [-pi, pi]: limit_period is exercised
+    b[:7, 3:5] = torch.tensor([[0.32, 0.1], [0.64, 0.64], [1.28, 0.2], [2.56, 0.1], [0.001, 0.001], [5.12, 5.12], [10.24, 1.0]])
+    b = b.to(dev)
+    for scales in ([0.25], [0.25, 0.125, 0.0625], [0.5, 0.25]):
+        pooler = Pooler((7, 7, 2), scales, 2, 8.0)
+        p = b.clone()
+        p[:, 0:6] *= 50.0
+        want_rois = convert_to_roi_format(p)
+        got_rois, got_levels = roi_prepare(b, 50.0, scales, 8.0)
+        assert torch.equal(got_rois, want_rois)
+        if len(scales) > 1:
+            assert torch.equal(got_levels.long(), pooler.map_levels(p))
+            assert len(torch.unique(got_levels)) > 1
+        else:
+            assert got_levels is None
+    assert roi_prepare(b[:0], 50.0, [0.25, 0.125], 8.0)[0].shape == (0, 8)
