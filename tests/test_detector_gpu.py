@@ -176,3 +176,30 @@ def test_two_lane_pass_matches_the_one_stream_pass_to_the_bit(setup, dev):
         assert SCN.Convolution_prepare(size, (size - 2) // 2 + 1, [2, 2, 2], [2, 2, 2], net.metadata) > 0
     net.metadata.set_geometry_stream(None)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("n_points", [60, 700, 5000])
+def test_tiny_buildings_run_through_every_path(setup, dev, n_points):
+    """Few points (coarse levels of one or two sites, far fewer anchors than the pre-NMS top-k, possibly no detection):
+    the two-lane pass, the one-stream pass and the staged pipeline all run and agree to the bit."""
+    from detection_3d_amd.serving import BuildingPipeline
+    from detection_3d_amd.sparseconvnet import fpn_net
+    from detection_3d_amd.synthetic import make_scene
+    from detection_3d_amd.voxelize import voxelize
+    cfg, model = setup[0], setup[1]
+    pcl = torch.from_numpy(make_scene(31, 40000)[:n_points].copy()).to(dev)
+    res = {}
+    try:
+        for two in (True, False):
+            fpn_net.TWO_LANE = two
+            c, f = voxelize(pcl, cfg.SPARSE3D.VOXEL_SCALE, cfg.SPARSE3D.VOXEL_FULL_SCALE)
+            res[two] = model([c, f])
+            torch.cuda.synchronize()
+    finally:
+        fpn_net.TWO_LANE = True
+    piped = BuildingPipeline(model, cfg, in_flight=2, device=dev).map([pcl, pcl, pcl])
+    torch.cuda.synchronize()
+    for other in [res[False]] + piped:
+        for k in ("bbox3d", "scores", "labels"):
+            assert other[k].shape == res[True][k].shape and torch.equal(other[k], res[True][k]), (n_points, k)
+    assert res[True]["bbox3d"].shape[1] == 7 and torch.isfinite(res[True]["bbox3d"]).all()
