@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void k_conv_reduce(const float *__restrict__ p
   *(f32x4 *)(out + o) = acc;
 }
 
-static constexpr int kSplitTargetWaves = 2048;  // below this many waves the launch is offset-split
+static constexpr int kSplitTargetWaves = 4096;  // below this many waves the launch is offset-split
 
 // d3d_conv_time_next: HIP events the next k_conv launch of this thread is bracketed with (measurement only)
 static thread_local hipEvent_t t_time_start = nullptr, t_time_stop = nullptr;
