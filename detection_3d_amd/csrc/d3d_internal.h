@@ -183,26 +183,38 @@ __device__ __forceinline__ uint32_t hash_key(uint64_t k) {
   return ((uint32_t)k << 3) | intra;
 }
 static constexpr uint32_t kProbeStep = 8;
+// Probe sequence: whole groups (same position inside the 2x2x2 block) first; after one full round over the cap/8
+// groups the position moves on by one slot, so that the sequence reaches every slot of the table and an insertion
+// terminates for ANY key set up to the table's capacity (a scene whose voxels all share one coordinate parity would
+// otherwise fill its eighth of the table and probe for ever).
+__device__ __forceinline__ uint32_t probe_next(uint32_t slot, uint32_t &round, int cap) {
+  slot = (slot + kProbeStep) & (uint32_t)(cap - 1);
+  if (++round == (uint32_t)cap / kProbeStep) {
+    round = 0;
+    slot = (slot + 1) & (uint32_t)(cap - 1);
+  }
+  return slot;
+}
 // returns the slot holding `key` (inserting it if absent)
 __device__ __forceinline__ int hash_insert(HashEntry *tab, int cap, uint64_t key) {
-  uint32_t slot = hash_key(key) & (uint32_t)(cap - 1);
+  uint32_t slot = hash_key(key) & (uint32_t)(cap - 1), round = 0;
   while (true) {
     unsigned long long prev = atomicCAS((unsigned long long *)&tab[slot].key,
                                         (unsigned long long)kEmptyKey, (unsigned long long)key);
     if (prev == kEmptyKey || prev == key) return (int)slot;
-    slot = (slot + kProbeStep) & (uint32_t)(cap - 1);
+    slot = probe_next(slot, round, cap);
   }
 }
 // returns the site id stored for `key`, or -1 (one 16-B load per probed slot)
 __device__ __forceinline__ int hash_find(const HashEntry *__restrict__ tab, int cap, uint64_t key) {
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  uint32_t slot = hash_key(key) & (uint32_t)(cap - 1);
+  uint32_t slot = hash_key(key) & (uint32_t)(cap - 1), round = 0;
   while (true) {
     const u32x4 e = *(const u32x4 *)&tab[slot];
     const uint64_t k = ((uint64_t)e[1] << 32) | e[0];
     if (k == key) return (int)e[2];
     if (k == kEmptyKey) return -1;
-    slot = (slot + kProbeStep) & (uint32_t)(cap - 1);
+    slot = probe_next(slot, round, cap);
   }
 }
 

@@ -282,6 +282,93 @@ __global__ void k_conv_fill(const int32_t *__restrict__ loc, long n_entries, Con
   nbr_dec[(size_t)i * K + off] = oid;
 }
 
+// The whole strided-grid build of a SMALL level in one single-workgroup launch: table + rulebook initialisation,
+// insertion, first-touch flags, their exclusive scan in entry order, site numbering, and the forward / decoded
+// rulebook fill -- what the large path spreads over 11 launches (3 fills, k_conv_insert, k_flag_first, 3 scan kernels,
+// k_conv_assign, k_conv_fill).  The coarse pyramid levels are pure latency (each launch a dependent step of the chain
+// the host waits on for the site count), so fewer steps is what matters; the results are the large path's, bit for bit.
+// Threads keep their entries' slots in registers; table fields other threads wrote are read with agent-scope atomic
+// loads (L2), never through a possibly stale L1 line.
+static constexpr int kSmallGrid = 4096;                        // entries one workgroup takes (16 k: slower than the 11 launches)
+static constexpr int kSmallGridEPT = kSmallGrid / 1024;
+__global__ __launch_bounds__(1024) void k_conv_grid_small(const int32_t *__restrict__ loc, int n_entries, ConvGeom g,
+                                                          int K, int n_in, HashEntry *tab, int cap,
+                                                          int32_t *__restrict__ loc_out, int32_t *__restrict__ nbr_fwd,
+                                                          int32_t *__restrict__ nbr_dec, int32_t *__restrict__ total) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u32x4 ones = {~0u, ~0u, ~0u, ~0u};
+  for (int i = tid; i < cap; i += 1024) *(u32x4 *)&tab[i] = ones;
+  for (int i = tid; i < n_in * K + 1; i += 1024) nbr_dec[i] = -1;
+  for (int i = tid; i < n_entries * K + 1; i += 1024) nbr_fwd[i] = -1;      // n_out <= n_entries rows are read later
+  __threadfence();
+  __syncthreads();
+  int slot_r[kSmallGridEPT];
+#pragma unroll
+  for (int it = 0; it < kSmallGridEPT; it++) {
+    const int e = it * 1024 + tid;
+    int slot = -1;
+    if (e < n_entries) {
+      const int32_t *p = loc + (size_t)(e / g.max_out) * 4;
+      int o[3], off;
+      if (conv_entry(g, p, e % g.max_out, o, &off)) {
+        slot = hash_insert(tab, cap, pack_key(p[3], o[0], o[1], o[2]));
+        atomicMin(&tab[slot].first, (uint32_t)e);
+      }
+    }
+    slot_r[it] = slot;
+  }
+  __threadfence();
+  __syncthreads();
+  int base = 0;
+#pragma unroll
+  for (int it = 0; it < kSmallGridEPT; it++) {
+    if (it * 1024 >= n_entries) break;                                       // block-uniform
+    const int e = it * 1024 + tid, slot = slot_r[it];
+    const bool first = slot >= 0 &&
+                       __hip_atomic_load(&tab[slot].first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)e;
+    const unsigned long long bal = __ballot(first);
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+      const int c = wsum[w];
+      before += w < wave ? c : 0;
+      all += c;
+    }
+    if (first) {
+      const int id = base + before + __popcll(bal & ((1ull << lane) - 1ull));
+      const int32_t *p = loc + (size_t)(e / g.max_out) * 4;
+      int o[3], off;
+      conv_entry(g, p, e % g.max_out, o, &off);
+      __hip_atomic_store(&tab[slot].val, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      loc_out[id * 4 + 0] = o[0];
+      loc_out[id * 4 + 1] = o[1];
+      loc_out[id * 4 + 2] = o[2];
+      loc_out[id * 4 + 3] = p[3];
+    }
+    base += all;
+    __syncthreads();
+  }
+  if (tid == 0) *total = base;
+  __threadfence();
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < kSmallGridEPT; it++) {
+    const int e = it * 1024 + tid, slot = slot_r[it];
+    if (slot < 0) continue;
+    const int i = e / g.max_out;
+    const int32_t *p = loc + (size_t)i * 4;
+    int o[3], off;
+    conv_entry(g, p, e % g.max_out, o, &off);
+    const int oid = __hip_atomic_load(&tab[slot].val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    nbr_fwd[(size_t)oid * K + off] = i;
+    nbr_dec[(size_t)i * K + off] = oid;
+  }
+}
+
 // a4. Submanifold neighbour probes (SubmanifoldConvolutionRules.h:13-45).  A 256-thread block owns 64
 // output sites; its 64*K probes are spread over the threads (independent loads in flight), the [site][k]
 // table is written coalesced, and the per-site offset masks are assembled in LDS.
@@ -1075,11 +1162,33 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
     D3D_ALLOC(nbr_dec, int32_t, A, (size_t)n_in * K + 1);
     go.tab = tab;
     go.loc = loc_out;
-    D3D_HIP_CHECK(hipMemsetAsync(tab, 0xFF, sizeof(HashEntry) * go.cap, s));
-    D3D_HIP_CHECK(hipMemsetAsync(nbr_dec, 0xFF, sizeof(int32_t) * ((size_t)n_in * K + 1), s));
+    const bool small = n_entries > 0 && n_entries <= kSmallGrid;   // one launch does it all (k_conv_grid_small)
+    if (!small) {
+      D3D_HIP_CHECK(hipMemsetAsync(tab, 0xFF, sizeof(HashEntry) * go.cap, s));
+      D3D_HIP_CHECK(hipMemsetAsync(nbr_dec, 0xFF, sizeof(int32_t) * ((size_t)n_in * K + 1), s));
+    }
     Plan p;
     int n_out = 0;
-    if (n_entries > 0) {
+    if (small) {
+      size_t raw_bytes = ((size_t)n_entries * K + 1) * sizeof(int32_t);
+      if (A.used + raw_bytes + (size_t)(1 << 20) > A.cap) {
+        set_error("metadata arena exhausted while building a strided rulebook");
+        return D3D_ERR_NOMEM;
+      }
+      int32_t *nbr_fwd = (int32_t *)(A.base + ((A.cap - raw_bytes) & ~size_t(255)));
+      CapGuard guard(A, (A.cap - raw_bytes) & ~size_t(255));
+      size_t mark = A.used;
+      D3D_ALLOC(total, int32_t, A, 1);
+      hipLaunchKernelGGL(k_conv_grid_small, dim3(1), dim3(1024), 0, s, gi->loc, (int)n_entries, geo, K, n_in, tab, go.cap,
+                         loc_out, nbr_fwd, nbr_dec, total);
+      D3D_LAUNCH_CHECK();
+      D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[0], total, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      D3D_HIP_CHECK(hipStreamSynchronize(s));
+      n_out = (int)*(int32_t *)&m->host_words[0];
+      A.used = mark;
+      int rc = finalize_plan(m, nbr_fwd, n_out, K, p, s, nullptr);
+      if (rc) return rc;
+    } else if (n_entries > 0) {
       // raw forward table staged at the far end of the arena (size known only after the scan:
       // bound it by n_entries rows)
       size_t raw_bytes = ((size_t)n_entries * K + 1) * sizeof(int32_t);

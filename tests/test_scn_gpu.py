@@ -275,3 +275,33 @@ def test_plan_and_conv_at_boundary_sizes(dev, n_sites):
         assert rel_err(got, want) < 2e-4
     else:
         assert got.shape == (1, cout)          # one site: the unbiased variance is undefined (reference: NaN)
+
+
+def test_one_parity_sites_fill_their_table_class_and_still_terminate(dev):
+    """Every voxel on even coordinates: all keys fall into ONE of the eight position classes of the locality-preserving
+    hash, i.e. 4x more keys than that class has slots.  The probe sequence moves on to the other classes
+    (probe_next), so the input layer, the submanifold probes and a strided grid still terminate and match the oracle."""
+    import ctypes
+    from detection_3d_amd._lib import check, ints, lib, stream_of
+    size = (64, 64, 16)
+    rng = np.random.RandomState(4)
+    cells = rng.permutation(32 * 32 * 8)[:3000]
+    coords = np.stack([2 * (cells // 256), 2 * ((cells // 8) % 32), 2 * (cells % 8), np.zeros_like(cells)], 1).astype(np.int64)
+    feats = rng.randn(coords.shape[0], 9).astype(np.float32)
+    t = _input(dev, coords, feats, size)
+    sop, loc = oracle.input_sites(coords)
+    assert np.array_equal(t.get_spatial_locations().cpu().numpy(), loc.astype(np.int64))
+    m = t.metadata
+    nr = ctypes.c_long(0)
+    check(lib().d3d_subm_prepare(m._h, ints(size), ints([3, 3, 3]), stream_of(), ctypes.byref(nr)))
+    nbr, total = oracle.subm_nbr(loc, [3, 3, 3])
+    assert nr.value == total == loc.shape[0]                 # even coordinates: no two sites are neighbours
+    out_size = [32, 32, 8]
+    n_out = ctypes.c_int(0)
+    check(lib().d3d_conv_prepare(m._h, ints(size), ints(out_size), ints([2, 2, 2]), ints([2, 2, 2]), stream_of(),
+                                 ctypes.byref(n_out), None))
+    lo, ru = oracle.conv_rules(loc, [2, 2, 2], [2, 2, 2], out_size)
+    assert n_out.value == lo.shape[0] == 3000
+    assert np.array_equal(m.getSpatialLocations(out_size).cpu().numpy(), lo.astype(np.int64))
+    got = canon_rules(m.export_rules(1, size, [2, 2, 2], [2, 2, 2]).cpu().numpy())
+    assert np.array_equal(got, canon_rules(ru))
