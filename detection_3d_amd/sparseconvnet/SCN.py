@@ -331,9 +331,7 @@ def SubmanifoldConvolution_updateOutput(spatial_size, filter_size, m, input_feat
     macs = ctypes.c_double(0)
     prof = PROFILER
     want = ctypes.byref(macs) if ((prof is not None and prof.learn) or COUNT_MACS) else None
-    if prof is not None:   # keep the rulebook build and the rule-count read-back out of the timed launch
-        if prof.wants("subm", fv, cin, cout):
-            check(lib().d3d_subm_prepare(m._h, ints(size), ints(filt), stream_of(), None))
+    if prof is not None:   # the library records the events around the k_conv launch itself (after any rulebook build)
         t0 = prof.begin("subm", fv, cin, cout)
     check(lib().d3d_subm_conv_forward(m._h, ints(size), ints(filt), ptr(input_features), cin, ptr(packed),
                                       cout, ptr(residual), ptr(output_features), stream_of(), want,
@@ -405,7 +403,6 @@ def Deconvolution_updateOutput(input_size, output_size, filter_size, filter_stri
     prof = PROFILER
     want = ctypes.byref(macs) if ((prof is not None and prof.learn) or COUNT_MACS) else None
     if prof is not None:
-        check(lib().d3d_deconv_prepare(m._h, ints(isz), ints(osz), ints(filt), ints(st), stream_of(), None))
         t0 = prof.begin("deconv", fv, cin, cout)
     check(lib().d3d_deconv_forward(m._h, ints(isz), ints(osz), ints(filt), ints(st), ptr(input_features),
                                    cin, ptr(packed), cout, ptr(residual), ptr(output_features), stream_of(),
