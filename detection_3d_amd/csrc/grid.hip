@@ -156,6 +156,21 @@ static inline int next_pow2(long v) {
 }
 static inline dim3 grid1d(long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
+// 0xFF fill of hash tables and rulebook arrays.  hipMemsetAsync's fill kernel reaches ~0.3 TB/s on the 12-16 MB arrays
+// of the fine levels (53 us for a 16 MB table); 16-byte stores from enough workgroups run at HBM speed.
+__global__ __launch_bounds__(256) void k_fill_ones(uint4 *__restrict__ p, size_t n16) {
+  const uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+static hipError_t fill_ones(void *ptr, size_t bytes, hipStream_t s) {
+  if (bytes < ((size_t)1 << 18) || ((uintptr_t)ptr & 15)) return hipMemsetAsync(ptr, 0xFF, bytes, s);
+  const size_t n16 = bytes / 16;
+  const unsigned blocks = (unsigned)std::min<size_t>((n16 + 1023) / 1024, 256 * 16);
+  hipLaunchKernelGGL(k_fill_ones, dim3(blocks), dim3(256), 0, s, (uint4 *)ptr, n16);
+  if (bytes & 15) return hipMemsetAsync((char *)ptr + n16 * 16, 0xFF, bytes & 15, s);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------
 // a2. Input layer: hash insert + first-occurrence numbering (IOLayersRules.h:72-95).
 __global__ void k_insert_points(const int64_t *__restrict__ coords, int n, int ncols,
@@ -942,7 +957,7 @@ int d3d_input_layer_build(d3d_meta *m, const int64_t *coords, int n, int ncols, 
   m->in_mode = mode;
   m->in_off = in_off;
   m->in_idx = in_idx;
-  D3D_HIP_CHECK(hipMemsetAsync(tab, 0xFF, sizeof(HashEntry) * g.cap, s));
+  D3D_HIP_CHECK(fill_ones(tab, sizeof(HashEntry) * g.cap, s));
   int n_active = 0;
   if (n > 0) {
     size_t mark = A.used;
@@ -1164,8 +1179,8 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
     go.loc = loc_out;
     const bool small = n_entries > 0 && n_entries <= kSmallGrid;   // one launch does it all (k_conv_grid_small)
     if (!small) {
-      D3D_HIP_CHECK(hipMemsetAsync(tab, 0xFF, sizeof(HashEntry) * go.cap, s));
-      D3D_HIP_CHECK(hipMemsetAsync(nbr_dec, 0xFF, sizeof(int32_t) * ((size_t)n_in * K + 1), s));
+      D3D_HIP_CHECK(fill_ones(tab, sizeof(HashEntry) * go.cap, s));
+      D3D_HIP_CHECK(fill_ones(nbr_dec, sizeof(int32_t) * ((size_t)n_in * K + 1), s));
     }
     Plan p;
     int n_out = 0;
@@ -1211,7 +1226,7 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
       D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[0], total, sizeof(int32_t), hipMemcpyDeviceToHost, s));
       D3D_HIP_CHECK(hipStreamSynchronize(s));
       n_out = (int)*(int32_t *)&m->host_words[0];
-      D3D_HIP_CHECK(hipMemsetAsync(nbr_fwd, 0xFF, sizeof(int32_t) * ((size_t)n_out * K + 1), s));
+      D3D_HIP_CHECK(fill_ones(nbr_fwd, sizeof(int32_t) * ((size_t)n_out * K + 1), s));
       hipLaunchKernelGGL(k_conv_fill, grid1d(n_entries), dim3(256), 0, s, gi->loc, n_entries, geo, K, eslot, tab, nbr_fwd, nbr_dec);
       D3D_LAUNCH_CHECK();
       A.used = mark;
