@@ -80,14 +80,21 @@ __global__ __launch_bounds__(kStatThreads) void k_bn_stats(const float *__restri
           ss[j] += d * d;
         }
     }
-    for (; r < r1; r += RL) {
-      const f32x4 v = *(const f32x4 *)(x + (size_t)r * C + g4 * 4);
+    if (r < r1) {   // at most 3 passes left: their loads go out together too (absent rows add exact zeros)
+      f32x4 v[3];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const double d = (double)v[j];
-        s[j] += d;
-        ss[j] += d * d;
+      for (int u = 0; u < 3; u++) {
+        const int rr = r + u * RL;
+        v[u] = rr < r1 ? *(const f32x4 *)(x + (size_t)rr * C + g4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
+#pragma unroll
+      for (int u = 0; u < 3; u++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const double d = (double)v[u][j];
+          s[j] += d;
+          ss[j] += d * d;
+        }
     }
     // rows of one channel group live in lanes cl, cl+LPR, ... of every wave: xor-butterfly inside the wave
     // (both partners compute the same sum), then one LDS entry per wave (or per row lane when LPR >= 64)
