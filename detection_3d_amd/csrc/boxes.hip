@@ -605,6 +605,72 @@ int d3d_rotate_nms_3d_sorted(const float *boxes, int n, float thresh, int max_ke
                                    scratch_bytes, stream);
 }
 
+// ---- box-head post-processing glue (inference.py:113-148), three launches instead of ~20 tensor ops ----
+// masked class scores, class-major: sc[j][i] = prob[i][j+1] if > thresh else -1; counts[j] = candidates of class j+1
+__global__ __launch_bounds__(256) void k_post_scores(const float *__restrict__ prob, int K, int nc, float thresh,
+                                                     float *__restrict__ sc, int32_t *__restrict__ counts) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  bool c = false;
+  if (i < K) {
+    const float v = prob[(size_t)i * nc + j + 1];
+    c = v > thresh;
+    sc[(size_t)j * K + i] = c ? v : -1.f;
+  }
+  const unsigned long long bal = __ballot(c);
+  if ((threadIdx.x & 63) == 0 && bal) atomicAdd(counts + j, __popcll(bal));
+}
+// order[j][i] = box index (RoI idx[j][i], class j+1) in the [K, nc] layout of the decoded boxes
+__global__ __launch_bounds__(256) void k_post_order(const int64_t *__restrict__ idx, int K, int nc, int nseg,
+                                                    int32_t *__restrict__ order) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)nseg * K) return;
+  order[t] = (int32_t)(idx[t] * nc + (int64_t)(t / K) + 1);
+}
+// survivors of the batched NMS, class-major in selection order: flat box index + score, padding = (0, -1)
+__global__ __launch_bounds__(256) void k_post_gather(const int32_t *__restrict__ keep, const int32_t *__restrict__ nk,
+                                                     int nseg, int n_max, const float *__restrict__ prob_flat,
+                                                     float *__restrict__ s_all, int64_t *__restrict__ flat_all) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nseg * n_max) return;
+  const bool valid = (t % n_max) < nk[t / n_max];
+  const int f = valid ? keep[t] : 0;
+  flat_all[t] = f;
+  s_all[t] = valid ? prob_flat[f] : -1.f;
+}
+
+int d3d_post_scores(const float *prob, int K, int nc, float thresh, float *sc, int32_t *counts, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(K >= 0 && nc >= 2, "post_scores: bad shape");
+  D3D_REQUIRE(counts, "post_scores: null pointer");
+  D3D_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int32_t) * (nc - 1), s));
+  if (K == 0) return D3D_OK;
+  D3D_REQUIRE(prob && sc, "post_scores: null pointer");
+  hipLaunchKernelGGL(k_post_scores, dim3((K + 255) / 256, nc - 1), dim3(256), 0, s, prob, K, nc, thresh, sc, counts);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+int d3d_post_order(const int64_t *idx, int K, int nc, int32_t *order, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(K >= 0 && nc >= 2, "post_order: bad shape");
+  if (K == 0) return D3D_OK;
+  D3D_REQUIRE(idx && order, "post_order: null pointer");
+  const long total = (long)(nc - 1) * K;
+  hipLaunchKernelGGL(k_post_order, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, idx, K, nc, nc - 1, order);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+int d3d_post_gather(const int32_t *keep, const int32_t *n_keep, int segments, int n_max, const float *prob_flat,
+                    float *scores, int64_t *flat, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(segments >= 0 && n_max >= 0, "post_gather: bad shape");
+  if (segments == 0 || n_max == 0) return D3D_OK;
+  D3D_REQUIRE(keep && n_keep && prob_flat && scores && flat, "post_gather: null pointer");
+  hipLaunchKernelGGL(k_post_gather, dim3((segments * n_max + 255) / 256), dim3(256), 0, s, keep, n_keep, segments, n_max,
+                     prob_flat, scores, flat);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
 int d3d_box_decode(const float *enc, const float *anchors, int n, const float *weights_host,
                    float clip, float *out, void *stream) {
   hipStream_t s = (hipStream_t)stream;

@@ -20,6 +20,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import box_ops
+from ._lib import check, lib, ptr, stream_of
 from . import sparseconvnet as scn
 from . import training as T
 from .config import class_to_label
@@ -416,25 +417,51 @@ class PostProcessor(nn.Module):
             z = prob.new_zeros
             return {"bbox3d": z((0, 7)), "scores": z((0,)), "labels": torch.zeros(0, dtype=torch.int64, device=prob.device)}
         # the per-class loop of inference.py:113-139 as ONE batched NMS: class j's candidates (prob > thresh) in
-        # descending score order (ties: lower RoI first) are a segment of box indices roi*nc + j
+        # descending score order (ties: lower RoI first) are a segment of box indices roi*nc + j; the glue around the
+        # sort, the NMS and the top-k is three library launches (d3d_post_*), bit-identical to _select_reference
+        dev, prob = prob.device, prob.contiguous()
+        sc = torch.empty((nc - 1, K), dtype=torch.float32, device=dev)
+        counts = torch.empty((nc - 1,), dtype=torch.int32, device=dev)
+        check(lib().d3d_post_scores(ptr(prob), K, nc, float(self.score_thresh), ptr(sc), ptr(counts), stream_of()))
+        idx = torch.sort(sc, dim=1, descending=True, stable=True)[1]
+        order = torch.empty((nc - 1, K), dtype=torch.int32, device=dev)
+        check(lib().d3d_post_order(ptr(idx), K, nc, ptr(order), stream_of()))
+        n_max = min(K, 2000)                                                     # pre_max_size of rotate_nms_3d
+        keep, nk = box_ops.nms_3d_batched(boxes.view(-1, 7), order, counts, n_max, self.nms, self.nms_aug_thickness,
+                                          500)                                   # post_max_size (boxlist_ops_3d.py)
+        s_all = torch.empty(((nc - 1) * n_max,), dtype=torch.float32, device=dev)
+        flat_all = torch.empty(((nc - 1) * n_max,), dtype=torch.int64, device=dev)
+        check(lib().d3d_post_gather(ptr(keep), ptr(nk), nc - 1, n_max, ptr(prob), ptr(s_all), ptr(flat_all), stream_of()))
+        if 0 < self.detections_per_img < s_all.shape[0]:                         # :140-148 without a second read-back:
+            # the D-th largest score; with fewer than D survivors it is a padding entry (-1) and every survivor stays
+            thresh = torch.topk(s_all, self.detections_per_img, sorted=True)[0][-1]
+            sel = s_all >= thresh.clamp_min(0.0)                                 # survivors have scores > 0, padding -1
+        else:
+            sel = s_all >= 0.0
+        flat = flat_all[sel]                                                     # the one host synchronisation
+        b, s, l = boxes.view(-1, 7)[flat], prob.reshape(-1)[flat], flat % nc
+        return {"bbox3d": b, "scores": s, "labels": l}
+
+    def _select_reference(self, prob, boxes):
+        """The same selection spelled in tensor ops (what forward ran before the d3d_post_* launches; kept as the
+        parity reference of tests/test_detector_gpu.py)."""
+        K, nc = prob.shape
         sc = prob[:, 1:].t().contiguous()                                        # [nc-1, K]
         cand = sc > self.score_thresh
         idx = torch.sort(torch.where(cand, sc, sc.new_full((), -1.0)), dim=1, descending=True, stable=True)[1]
         order = (idx * nc + torch.arange(1, nc, device=prob.device).view(-1, 1)).to(torch.int32).contiguous()
         counts = cand.sum(1).to(torch.int32)
-        n_max = min(K, 2000)                                                     # pre_max_size of rotate_nms_3d
-        keep, nk = box_ops.nms_3d_batched(boxes.view(-1, 7), order, counts, n_max, self.nms, self.nms_aug_thickness,
-                                          500)                                   # post_max_size (boxlist_ops_3d.py)
+        n_max = min(K, 2000)
+        keep, nk = box_ops.nms_3d_batched(boxes.view(-1, 7), order, counts, n_max, self.nms, self.nms_aug_thickness, 500)
         valid = torch.arange(keep.shape[1], device=prob.device).view(1, -1) < nk.view(-1, 1)
         flat_all = torch.where(valid, keep, torch.zeros_like(keep)).long().view(-1)   # class-major, selection order
         s_all = torch.where(valid.view(-1), prob.reshape(-1)[flat_all], prob.new_full((), -1.0))
-        if 0 < self.detections_per_img < s_all.shape[0]:                         # :140-148 without a second read-back:
-            # kthvalue(s, n - D + 1) is the D-th largest score; with fewer than D survivors it is a padding entry (-1)
+        if 0 < self.detections_per_img < s_all.shape[0]:
             thresh = torch.topk(s_all, self.detections_per_img, sorted=True)[0][-1]
             sel = valid.view(-1) & (s_all >= thresh)
         else:
             sel = valid.view(-1)
-        flat = flat_all[sel]                                                     # the one host synchronisation
+        flat = flat_all[sel]
         b, s, l = boxes.view(-1, 7)[flat], prob.reshape(-1)[flat], flat % nc
         return {"bbox3d": b, "scores": s, "labels": l}
 

@@ -273,6 +273,17 @@ int d3d_rotate_nms_3d_batched(const float *boxes, const int32_t *order, int stri
                               int max_keep, int32_t *keep, int32_t *n_keep, void *scratch,
                               size_t scratch_bytes, void *stream);
 size_t d3d_nms_batched_scratch_bytes(int segments, int n_max);
+/* Box-head post-processing glue around the batched NMS (roi_heads/box_head_3d/inference.py:113-148), one launch each:
+ * post_scores: sc[(nc-1), K] = prob[i][j+1] if > thresh else -1 (class-major), counts[nc-1] = candidates per class
+ *              (`inds = scores[:, j] > score_thresh`, :118);
+ * post_order:  order[j][i] = idx[j][i] * nc + j + 1, the box index of class j+1's i-th best RoI (idx = stable
+ *              descending argsort of sc rows) in the [K, nc] box layout -- the segments d3d_rotate_nms_3d_batched takes;
+ * post_gather: survivors class-major in selection order: flat[t] = keep[t], scores[t] = prob_flat[keep[t]] for
+ *              t % n_max < n_keep[t / n_max], else (0, -1) (:140-148 then picks the top detections_per_img). */
+int d3d_post_scores(const float *prob, int K, int nc, float thresh, float *sc, int32_t *counts, void *stream);
+int d3d_post_order(const int64_t *idx, int K, int nc, int32_t *order, void *stream);
+int d3d_post_gather(const int32_t *keep, const int32_t *n_keep, int segments, int n_max, const float *prob_flat,
+                    float *scores, int64_t *flat, void *stream);
 /* a14. BoxCoder3D.decode (maskrcnn_benchmark/modeling/box_coder_3d.py:38-65). */
 int d3d_box_decode(const float *enc, const float *anchors, int n, const float *weights_host,
                    float clip, float *out, void *stream);
