@@ -596,6 +596,7 @@ int d3d_input_layer_backward(d3d_meta *m, const float *d_out, int planes, float 
   }
   if (m->in_active == 0) return D3D_OK;
   D3D_REQUIRE(d_out && d_in, "null gradient pointer");
+  if (int rc = ensure_point_lists(m, s)) return rc;
   long total = (long)m->in_active * planes;
   hipLaunchKernelGGL(k_input_backward, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_out, planes,
                      m->in_off, m->in_idx, m->in_active, m->in_mode == 4 ? 1 : 0, d_in);

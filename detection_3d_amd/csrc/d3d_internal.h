@@ -137,6 +137,9 @@ struct d3d_meta {
   // input layer
   int in_n = 0, in_mode = 0, in_active = 0;
   int32_t *in_off = nullptr, *in_idx = nullptr;
+  int32_t *in_pslot = nullptr;   // hash slot of every input point (input for the point lists, built on first use)
+  bool in_lists = false;         // in_off / in_idx filled (ensure_point_lists)
+  d3d::Size3 in_size = {0, 0, 0};  // spatial size of the input grid
   // pinned host words for size read-backs
   long *host_words = nullptr;
 };
@@ -157,6 +160,7 @@ int get_deconv_plan(d3d_meta *m, const int *fine_size, const int *filt, const in
 
 int grid_extent(d3d_meta *m, Grid &g, hipStream_t s);  // grid.hip: ensures g.extent
 int check_build_stream(d3d_meta *m, hipStream_t s, const char *what);
+int ensure_point_lists(d3d_meta *m, hipStream_t s);
 Arena &lane_arena(d3d_meta *m, hipStream_t s);
 
 // conv.hip

@@ -884,7 +884,8 @@ int d3d_meta_clear(d3d_meta *m) {
   m->plans.clear();
   m->strided_raw.clear();
   m->in_n = m->in_mode = m->in_active = 0;
-  m->in_off = m->in_idx = nullptr;
+  m->in_off = m->in_idx = m->in_pslot = nullptr;
+  m->in_lists = false;
   return D3D_OK;
 }
 int d3d_meta_set_geometry_stream(d3d_meta *m, void *stream, int enable) {
@@ -951,6 +952,10 @@ int d3d_input_layer_build(d3d_meta *m, const int64_t *coords, int n, int ncols, 
   D3D_ALLOC(loc, int32_t, A, (size_t)n * 4 + 4);
   D3D_ALLOC(in_off, int32_t, A, (size_t)n + 2);
   D3D_ALLOC(in_idx, int32_t, A, (size_t)n + 1);
+  D3D_ALLOC(pslot, int32_t, A, (size_t)n + 1);
+  m->in_pslot = pslot;
+  m->in_lists = false;
+  m->in_size = Size3{size[0], size[1], size[2]};
   g.tab = tab;
   g.loc = loc;
   m->in_n = n;
@@ -961,14 +966,9 @@ int d3d_input_layer_build(d3d_meta *m, const int64_t *coords, int n, int ncols, 
   int n_active = 0;
   if (n > 0) {
     size_t mark = A.used;
-    D3D_ALLOC(pslot, int32_t, A, n);
     D3D_ALLOC(flag, int32_t, A, n);
     D3D_ALLOC(rank, int32_t, A, n);
     D3D_ALLOC(total, int32_t, A, 1);
-    D3D_ALLOC(psite, uint32_t, A, n);
-    D3D_ALLOC(psite_sorted, uint32_t, A, n);
-    D3D_ALLOC(iota, int32_t, A, n);
-    D3D_ALLOC(cnt, int32_t, A, (size_t)n + 1);
     hipLaunchKernelGGL(k_insert_points, grid1d(n), dim3(256), 0, s, coords, n, ncols, tab, g.cap, pslot);
     hipLaunchKernelGGL(k_flag_first, grid1d(n), dim3(256), 0, s, pslot, tab, n, flag);
     int rc = scan_exclusive_i32(flag, rank, n, total, A, s);
@@ -978,17 +978,6 @@ int d3d_input_layer_build(d3d_meta *m, const int64_t *coords, int n, int ncols, 
     D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[0], total, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     D3D_HIP_CHECK(hipStreamSynchronize(s));
     n_active = (int)*(int32_t *)&m->host_words[0];
-    // per-site point lists in input order: stable sort of point ids by site id
-    D3D_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int32_t) * ((size_t)n_active + 1), s));
-    hipLaunchKernelGGL(k_point_site, grid1d(n), dim3(256), 0, s, pslot, tab, n, psite, cnt);
-    hipLaunchKernelGGL(k_iota, grid1d(n), dim3(256), 0, s, iota, n);
-    rc = scan_exclusive_i32(cnt, in_off, n_active + 1, nullptr, A, s);
-    if (rc) return rc;
-    int bits = 1;
-    while ((1L << bits) < n_active) bits++;
-    rc = sort_pairs_u32(psite, psite_sorted, iota, in_idx, n, bits, A, s, false);
-    if (rc) return rc;
-    D3D_LAUNCH_CHECK();
     A.used = mark;
   }
   g.n = n_active;
@@ -996,6 +985,51 @@ int d3d_input_layer_build(d3d_meta *m, const int64_t *coords, int n, int ncols, 
   m->grids[Size3{size[0], size[1], size[2]}] = g;
   *n_active_host = n_active;
   return D3D_OK;
+}
+
+}  // extern "C"
+
+namespace d3d {
+// Per-site point lists in input order (stable sort of point ids by site id), built by the first consumer on ITS
+// stream with temporaries from that stream's lane of the arena: the grid exists as soon as d3d_input_layer_build
+// returns, so a caller may start the level-0 rulebook on another stream while the lists are sorted here.
+int ensure_point_lists(d3d_meta *m, hipStream_t s) {
+  if (m->in_lists || m->in_n == 0) return D3D_OK;
+  const int n = m->in_n, n_active = m->in_active;
+  auto it = m->grids.find(m->in_size);
+  D3D_REQUIRE(it != m->grids.end(), "input layer: grid not found");
+  Arena &A = lane_arena(m, s);
+  size_t mark = A.used;
+  D3D_ALLOC(psite, uint32_t, A, n);
+  D3D_ALLOC(psite_sorted, uint32_t, A, n);
+  D3D_ALLOC(iota, int32_t, A, n);
+  D3D_ALLOC(cnt, int32_t, A, (size_t)n + 1);
+  D3D_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int32_t) * ((size_t)n_active + 1), s));
+  hipLaunchKernelGGL(k_point_site, grid1d(n), dim3(256), 0, s, m->in_pslot, it->second.tab, n, psite, cnt);
+  hipLaunchKernelGGL(k_iota, grid1d(n), dim3(256), 0, s, iota, n);
+  int rc = scan_exclusive_i32(cnt, m->in_off, n_active + 1, nullptr, A, s);
+  if (rc) return rc;
+  int bits = 1;
+  while ((1L << bits) < n_active) bits++;
+  rc = sort_pairs_u32(psite, psite_sorted, iota, m->in_idx, n, bits, A, s, false);
+  if (rc) return rc;
+  D3D_LAUNCH_CHECK();
+  A.used = mark;
+  m->in_lists = true;
+  return D3D_OK;
+}
+}  // namespace d3d
+
+extern "C" {
+
+
+int d3d_input_layer_prepare(d3d_meta *m, void *stream) {
+  D3D_REQUIRE(m, "null metadata");
+  if (!m->in_off) {
+    set_error("input layer prepare before build");
+    return D3D_ERR_STATE;
+  }
+  return ensure_point_lists(m, (hipStream_t)stream);
 }
 
 int d3d_input_layer_forward(d3d_meta *m, const float *feats, int planes, float *out, void *stream) {
@@ -1007,6 +1041,7 @@ int d3d_input_layer_forward(d3d_meta *m, const float *feats, int planes, float *
   }
   if (m->in_active == 0) return D3D_OK;
   D3D_REQUIRE(feats && out, "null feature pointer");
+  if (int rc = ensure_point_lists(m, s)) return rc;
   hipLaunchKernelGGL(k_input_forward, grid1d((long)m->in_active * planes), dim3(256), 0, s, feats,
                      planes, m->in_off, m->in_idx, m->in_active, m->in_mode == 4 ? 1 : 0, out);
   D3D_LAUNCH_CHECK();
@@ -1020,6 +1055,7 @@ int d3d_input_layer_export(d3d_meta *m, int32_t *offsets, int32_t *idx, void *st
     set_error("input layer export before build");
     return D3D_ERR_STATE;
   }
+  if (int rc = ensure_point_lists(m, s)) return rc;
   hipLaunchKernelGGL(k_export_input, grid1d(m->in_active + 1), dim3(256), 0, s, m->in_off, offsets, m->in_active + 1);
   if (m->in_n) hipLaunchKernelGGL(k_export_input, grid1d(m->in_n), dim3(256), 0, s, m->in_idx, idx, m->in_n);
   D3D_LAUNCH_CHECK();

@@ -260,6 +260,21 @@ def _coords_to_device(coords, device):
     return coords.contiguous()
 
 
+_TLS = threading.local()
+
+
+def set_after_input_build(hook):
+    """hook(metadata, spatial_size) is called by this thread's next InputLayer_updateOutput calls between the grid
+    build (whose site count has just been read back) and the feature pass of the input layer -- where a caller can
+    start the level-0 rulebook on another stream (FPN_Net._forward_two_lane).  None removes it."""
+    _TLS.after_input_build = hook
+
+
+def InputLayer_prepare(m):
+    """d3d_input_layer_prepare: the input layer's per-site point lists, on the current stream."""
+    check(lib().d3d_input_layer_prepare(m._h, stream_of()))
+
+
 def InputLayer_updateOutput(m, spatial_size, input_coords, input_features, output_features,
                             batch_size, mode):
     """sparseconvnet.h:159-163.  input_coords int64 [N,3|4] on CPU or GPU."""
@@ -271,6 +286,9 @@ def InputLayer_updateOutput(m, spatial_size, input_coords, input_features, outpu
     check(lib().d3d_input_layer_build(m._h, ptr(coords), n, ncols, ints(_size3(spatial_size)),
                                       int(batch_size), int(mode), stream_of(), ctypes.byref(na)))
     m._in_active = na.value
+    hook = getattr(_TLS, "after_input_build", None)
+    if hook is not None:
+        hook(m, spatial_size)
     planes = input_features.shape[1]
     output_features.resize_(na.value, planes)
     feats = input_features.contiguous()

@@ -20,8 +20,7 @@ _GEO_STREAMS = {}   # (device, caller's stream) -> high-priority side stream
 
 
 def _is_gpu_input(net0):
-    t = net0[1] if isinstance(net0, (list, tuple)) else getattr(net0, "features", None)
-    return torch.is_tensor(t) and t.is_cuda
+    return isinstance(net0, (list, tuple)) and len(net0) > 1 and torch.is_tensor(net0[1]) and net0[1].is_cuda
 
 
 def _geometry_stream(main):
@@ -118,12 +117,33 @@ class FPN_Net(torch.nn.Module):
         read-backs no longer leave the GPU idle.  Same kernels on the same data as the one-stream pass
         (bit-identical).  Meanwhile the metadata accepts new grids on the side stream only and gives each stream its
         own part of the arena (d3d_meta_set_geometry_stream)."""
-        net = self.layers_in[0](net0)                       # input layer: grid of level 0
-        main = torch.cuda.current_stream(net.features.device)
+        main = torch.cuda.current_stream(net0[1].device)
         geo, pool = _geometry_stream(main)
+        plan0 = pool[-1]
+
+        started = []
+
+        def after_input_build(md, size):
+            # the level-0 grid exists: this stream starts on its 3x3x3 rulebook (hash probes + sort, ~0.4 ms) while the
+            # side stream sorts the input layer's point lists, which the feature pass then only has to wait for
+            started.append(md)
+            geo.wait_stream(main)
+            md.set_geometry_stream(geo.cuda_stream)
+            scn.SCN.SubmanifoldConvolution_prepare(size, (3,) * self.dimension, md)
+            with torch.cuda.stream(geo):
+                scn.SCN.InputLayer_prepare(md)
+                plan0.record(geo)
+            main.wait_event(plan0)
+
+        scn.SCN.set_after_input_build(after_input_build)
+        try:
+            net = self.layers_in[0](net0)                   # input layer: grid of level 0
+        finally:
+            scn.SCN.set_after_input_build(None)
         md = net.metadata
-        geo.wait_stream(main)
-        md.set_geometry_stream(geo.cuda_stream)
+        if not started:                                     # (an input layer that did not go through the hook)
+            geo.wait_stream(main)
+            md.set_geometry_stream(geo.cuda_stream)
         steps, events = self._geometry_steps(net, False), []
 
         def lane(k):        # level k is about to be enqueued: build its grid now (level k-1 is already in the queue)

@@ -71,6 +71,10 @@ size_t d3d_voxelize_scratch_bytes(int n);
 int d3d_input_layer_build(d3d_meta *m, const int64_t *coords, int n, int ncols,
                           const int *spatial_size_host, int batch_size, int mode, void *stream,
                           int *n_active_host);
+/* The per-site point lists d3d_input_layer_forward / _backward read (IOLayersRules.h:19-125 builds them with the
+ * grid) are built by the first call that needs them, on ITS stream; this builds them explicitly, e.g. on a side stream
+ * while the caller's stream already probes the level-0 rulebook.                                               */
+int d3d_input_layer_prepare(d3d_meta *m, void *stream);
 int d3d_input_layer_forward(d3d_meta *m, const float *feats, int planes, float *out, void *stream);
 /* debug exporter: rule table rows [count, idx0..] (IOLayersRules.h:112-124) as CSR.
  * offsets int32 [n_active+1], idx int32 [n].                                                 */
