@@ -246,7 +246,7 @@ static int launch_dw(const Plan &p, const float *in, int cin, const float *d_out
 // ------------------------------------------------------------------------------------------
 // BatchNorm backward (CPU/BatchNormalization.cpp:62-107): partial sums of d' = dOut * relu' and
 // (x - mean) d', fixed-order reduction, then the elementwise pass.
-static constexpr int kBnBwdBlocks = 512;
+static constexpr int kBnBwdBlocks = 128;
 __global__ __launch_bounds__(256) void k_bn_bwd_partial(const float *__restrict__ x, const float *__restrict__ y,
                                                         const float *__restrict__ dy, int rows, int C,
                                                         const float *__restrict__ mean, float leak,
