@@ -317,7 +317,8 @@ __global__ __launch_bounds__(1024) void k_conv_grid_small(const int32_t *__restr
   for (int i = tid; i < cap; i += 1024) *(u32x4 *)&tab[i] = ones;
   for (int i = tid; i < n_in * K + 1; i += 1024) nbr_dec[i] = -1;
   for (int i = tid; i < n_entries * K + 1; i += 1024) nbr_fwd[i] = -1;      // n_out <= n_entries rows are read later
-  __threadfence();
+  __syncthreads();   // every wave's stores have reached L2 ...
+  if (tid == 0) __threadfence();   // ... one agent-scope fence for the workgroup (as in k_bn_stats)
   __syncthreads();
   int slot_r[kSmallGridEPT];
 #pragma unroll
@@ -334,7 +335,8 @@ __global__ __launch_bounds__(1024) void k_conv_grid_small(const int32_t *__restr
     }
     slot_r[it] = slot;
   }
-  __threadfence();
+  __syncthreads();   // every wave's stores have reached L2 ...
+  if (tid == 0) __threadfence();   // ... one agent-scope fence for the workgroup (as in k_bn_stats)
   __syncthreads();
   int base = 0;
 #pragma unroll
@@ -368,7 +370,8 @@ __global__ __launch_bounds__(1024) void k_conv_grid_small(const int32_t *__restr
     __syncthreads();
   }
   if (tid == 0) *total = base;
-  __threadfence();
+  __syncthreads();   // every wave's stores have reached L2 ...
+  if (tid == 0) __threadfence();   // ... one agent-scope fence for the workgroup (as in k_bn_stats)
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < kSmallGridEPT; it++) {
