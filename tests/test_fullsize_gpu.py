@@ -109,6 +109,22 @@ def test_detector_is_deterministic_to_the_bit_at_full_size(scene, dev):
     for k in ("bbox3d", "scores", "labels"):
         assert torch.equal(r1[k], r2[k])
     assert r1["bbox3d"].shape[0] > 0
+    # the same building through the one-stream pass and through two buildings in flight: identical to the bit
+    from detection_3d_amd.serving import BuildingPipeline
+    from detection_3d_amd.sparseconvnet import fpn_net
+    try:
+        fpn_net.TWO_LANE = False
+        r3, mid3 = model([coords, feats], return_intermediates=True)
+    finally:
+        fpn_net.TWO_LANE = True
+    for a, b in zip(mid1["rpn_features"] + mid1["roi_features"], mid3["rpn_features"] + mid3["roi_features"]):
+        assert torch.equal(a.features, b.features)
+    cloud = torch.from_numpy(pcl).to(dev)
+    piped = BuildingPipeline(model, cfg, in_flight=2, device=dev).map([cloud, cloud, cloud])
+    torch.cuda.synchronize()
+    for other in [r3] + piped:
+        for k in ("bbox3d", "scores", "labels"):
+            assert torch.equal(r1[k], other[k])
     # NMS idempotence on the detector's own proposals (2000 candidates): survivors survive again, all of them
     from detection_3d_amd import box_ops
     props = mid1["proposals"]
