@@ -13,10 +13,18 @@ Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP events on the 
 the timed region) and, at N=1, `cpu_baseline` (the CPU oracle port on a bounded sample).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
 import time
+
+# host threads per rank: decided before any OpenMP runtime (torch's, the CPU oracle's) is loaded.  One rank may use the
+# CPU share of a one-GPU box (16); N ranks split the cores so that they do not fight for them.
+CPU_BASELINE_THREADS = 16
+_WORLD = max(1, int(os.environ.get("WORLD_SIZE", "1")))
+_HOST_THREADS = max(1, min(CPU_BASELINE_THREADS, (os.cpu_count() or 1) // _WORLD))
+os.environ["OMP_NUM_THREADS"] = str(_HOST_THREADS)
 
 import numpy as np
 import torch
@@ -43,16 +51,27 @@ def parse():
 
 
 def pmc_traffic(template):
-    """HBM-side bytes per launch of `template` from the committed PMC passes (profiles/r01_pmc_{fetch,write}.csv:
-    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` of this script, summed per kernel name, in KB).
-    gfx950 correction of MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts wide coalesced reads at half their bytes.
-    None when the files are absent."""
+    """-> (HBM-side bytes per launch of `template` or None, provenance string).  The PMC counters cannot be read from
+    inside the benchmark process, so the figure is replayed from the committed passes named by profiles/pmc_current.json
+    (`rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` of this script, summed per kernel name by
+    scripts/pmc_summary.py, in KB) -- but only while csrc/conv.hip still has the SHA-256 it had when they were taken;
+    otherwise traffic is null and the reason is reported.  gfx950 correction of MI355X_MICROARCH.md (HBM section):
+    FETCH_SIZE counts wide coalesced reads at half their bytes."""
     import csv
+    meta_path = os.path.join(ROOT, "profiles", "pmc_current.json")
+    if not os.path.exists(meta_path):
+        return None, "no profiles/pmc_current.json"
+    with open(meta_path) as f:
+        meta = json.load(f)
+    with open(os.path.join(ROOT, "detection_3d_amd", "csrc", "conv.hip"), "rb") as f:
+        sha = hashlib.sha256(f.read()).hexdigest()
+    if sha != meta.get("conv_hip_sha256"):
+        return None, f"stale: {meta.get('fetch_csv')} was taken for another csrc/conv.hip ({str(meta.get('conv_hip_sha256'))[:12]})"
     tot = 0.0
-    for name, factor in (("r01_pmc_fetch.csv", 2.0), ("r01_pmc_write.csv", 1.0)):
+    for name, factor in ((meta["fetch_csv"], 2.0), (meta["write_csv"], 1.0)):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
-            return None
+            return None, f"missing profiles/{name}"
         hit = None
         with open(path) as f:
             for row in csv.reader(f):
@@ -60,9 +79,10 @@ def pmc_traffic(template):
                     hit = float(row[3]) * 1024.0 * factor
                     break
         if hit is None:
-            return None
+            return None, f"kernel {template} not in profiles/{name}"
         tot += hit
-    return tot
+    return tot, (f"bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE of profiles/{meta['fetch_csv']} / {meta['write_csv']} "
+                 f"(separate --pmc passes, taken at {meta.get('taken_at', '?')}, conv.hip {sha[:12]})")
 
 
 def kernel_name(key):
@@ -74,7 +94,6 @@ def kernel_name(key):
             f"(Cin={cin}, Cout={cout}, all filter volumes)")
 
 
-CPU_BASELINE_THREADS = 16   # the CPU share of a one-GPU box
 CPU_BASELINE_BUILDINGS = 3   # bounded sample: ~13 s of wall time on 16 threads
 
 
@@ -82,8 +101,7 @@ def cpu_baseline(cfg, state_dict, n_points):
     """The CPU oracle port (oracle/detector_port.py) timed on this host's cores on a bounded sample:
     one scene of `n_points` points over the same 25 x 19 x 2.7 m footprint (same number of pyramid
     levels and head work as the 500 k-point workload, fewer active voxels)."""
-    threads = min(CPU_BASELINE_THREADS, os.cpu_count() or 1)
-    os.environ["OMP_NUM_THREADS"] = str(threads)      # read by the oracle's OpenMP runtime at load time
+    threads = _HOST_THREADS                           # OMP_NUM_THREADS was set before any OpenMP runtime loaded
     torch.set_num_threads(threads)
     import oracle
     from oracle.detector_port import OracleDetector
@@ -209,20 +227,24 @@ def main():
         # dominant sparse-conv kernel = the k_conv template instantiation (Cin, Cout) with the largest summed time;
         # all its launches (every filter volume / conv kind) are timed, so that the average launch duration is the
         # one `rocprofv3 --kernel-trace --stats` reports for that kernel name (profiles/r01_bench_kernel_stats.csv)
-        key, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
-        per_launch_ms = d["ms"] / d["calls"]
-        tflops = d["flops"] / d["calls"] / (per_launch_ms * 1e-3) / 1e12
-        gbs = d["bytes"] / d["calls"] / (per_launch_ms * 1e-3) / 1e9
-        roof = {"bound": "mfma", "achieved": round(tflops, 3), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tflops / FP32_MATRIX_PEAK_TFLOPS, 4),
-                "traffic": pmc_traffic(kernel_name(key).split(" (")[0].replace("d3d::", "")),
-                "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE of profiles/r01_pmc_*.csv)",
-                "kernel": kernel_name(key),
-                "launches_per_step": d["calls"] / args.steps, "avg_launch_us": round(per_launch_ms * 1e3, 1),
-                "algorithmic_gflop_per_launch": round(d["flops"] / d["calls"] / 1e9, 3),
-                "compulsory_GBps": round(gbs, 1), "compulsory_frac_of_hbm": round(gbs / HBM_PEAK_GBS, 4),
-                "all_sparse_conv_ms_per_step_warmup": None if conv_ms_warm is None else round(conv_ms_warm, 3),
-                "kernels_warmup": families}
+        if summ:
+            key, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
+            per_launch_ms = d["ms"] / d["calls"]
+            tflops = d["flops"] / d["calls"] / (per_launch_ms * 1e-3) / 1e12
+            gbs = d["bytes"] / d["calls"] / (per_launch_ms * 1e-3) / 1e9
+            traffic, traffic_src = pmc_traffic(kernel_name(key).split(" (")[0].replace("d3d::", ""))
+            roof = {"bound": "mfma", "achieved": round(tflops, 3), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tflops / FP32_MATRIX_PEAK_TFLOPS, 4),
+                    "traffic": traffic, "traffic_unit": traffic_src,
+                    "kernel": kernel_name(key),
+                    "launches_per_step": d["calls"] / args.steps, "avg_launch_us": round(per_launch_ms * 1e3, 1),
+                    "algorithmic_gflop_per_launch": round(d["flops"] / d["calls"] / 1e9, 3),
+                    "compulsory_GBps": round(gbs, 1), "compulsory_frac_of_hbm": round(gbs / HBM_PEAK_GBS, 4),
+                    "all_sparse_conv_ms_per_step_warmup": None if conv_ms_warm is None else round(conv_ms_warm, 3),
+                    "kernels_warmup": families}
+        else:       # nothing was timed (no steps): the headline line is still printed
+            roof = {"bound": "mfma", "achieved": None, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
+                    "traffic": None, "traffic_unit": "no sparse convolution was timed"}
         out = {
             "metric": "buildings/sec inference, 4c_fpn432", "value": round(world * args.steps / dt_max, 3),
             "unit": "buildings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -36,7 +36,7 @@ _SIGS = {
     "d3d_post_order": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp]),
     "d3d_post_gather": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]),
     "d3d_roi_prepare": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_float, c_float_p, ctypes.c_int, ctypes.c_float, vp, vp,
-                                       vp]),
+                                       vp, vp]),
     "d3d_voxelize": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_int_p, vp, vp,
                                     c_int_p, vp, ctypes.c_size_t, vp]),
     "d3d_voxelize_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int]),

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void k_roi_sparse_bwd(
 using namespace d3d;
 
 // Pooler pre-processing in one launch (what the reference spreads over ~25 tensor ops): metric yx_zb proposals ->
-// the op's RoI rows (batch 0, centre x, centre y, centre z, size x, size y, size z, yaw in degrees, in pixels of the
+// the op's RoI rows (batch id, centre x, centre y, centre z, size x, size y, size z, yaw in degrees, in pixels of the
 // full-resolution grid) and the FPN level of every RoI.  The arithmetic is the reference's, operation by operation in
 // fp32 (a division by a constant is the product with its fp32 reciprocal, as the tensor library evaluates it), so
 // that the result equals the host-side chain bit for bit (tests/test_boxes_gpu.py).
@@ -365,7 +365,8 @@ struct RoiPrepScales {
 };
 __global__ __launch_bounds__(256) void k_roi_prepare(const float *__restrict__ boxes, int n, float voxel_scale,
                                                      RoiPrepScales scales, int n_levels, float inv_canonical,
-                                                     float *__restrict__ rois, int32_t *__restrict__ levels) {
+                                                     float *__restrict__ rois, int32_t *__restrict__ levels,
+                                                     const int32_t *__restrict__ batch_ids) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float b[7];
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(256) void k_roi_prepare(const float *__restrict__ b
   float yaw = b[6] + kHalfPi;                                        // yx_zb -> standard (bounding_box_3d.py:221-242)
   yaw = yaw - floorf(yaw * kInvPi + 0.f) * kPi;                      // limit_period(yaw, 0, pi)
   float *r = rois + (size_t)i * 8;
-  r[0] = 0.f;
+  r[0] = batch_ids ? (float)batch_ids[i] : 0.f;        // example index of the RoI (poolers_3d.py:112-118)
   r[1] = b[1];
   r[2] = b[0];
   r[3] = b[2] + b[5] * 0.5f;
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(256) void k_roi_prepare(const float *__restrict__ b
 extern "C" {
 
 int d3d_roi_prepare(const float *boxes_metric, int n, float voxel_scale, const float *scales_host, int n_levels,
-                    float canonical_size, float *rois, int32_t *levels, void *stream) {
+                    float canonical_size, const int32_t *batch_ids, float *rois, int32_t *levels, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   D3D_REQUIRE(n >= 0 && n_levels >= 0 && n_levels <= 8, "roi_prepare: bad arguments (at most 8 levels)");
   if (n == 0) return D3D_OK;
@@ -412,7 +413,7 @@ int d3d_roi_prepare(const float *boxes_metric, int n, float voxel_scale, const f
   RoiPrepScales sc = {};
   for (int l = 0; l < n_levels; l++) sc.v[l] = scales_host[l];
   hipLaunchKernelGGL(k_roi_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, boxes_metric, n, voxel_scale, sc,
-                     n_levels, 1.f / canonical_size, rois, n_levels > 1 ? levels : nullptr);
+                     n_levels, 1.f / canonical_size, rois, n_levels > 1 ? levels : nullptr, batch_ids);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }

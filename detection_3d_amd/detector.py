@@ -43,11 +43,18 @@ class SeperateClassifier(object):
         for i, g in enumerate(groups):
             self.grouped_classes.append([num_input_classes + i] + g)
         self.group_num = len(self.grouped_classes)
-        self.total_classes = num_input_classes + self.group_num - 1
+        self.total_classes = self.seperated_num_classes_total = num_input_classes + self.group_num - 1
         self.class_nums = [len(g) for g in self.grouped_classes]
+        # original label -> (group, label inside the group) and back (:39-44)
+        self.org_labels_to_sep_labels = torch.full((self.total_classes, 2), -1, dtype=torch.int64)
+        self.sep_labels_to_org_labels = [torch.tensor(g, dtype=torch.int64) for g in self.grouped_classes]
+        for g, classes in enumerate(self.grouped_classes):
+            for i, c in enumerate(classes):
+                self.org_labels_to_sep_labels[c] = torch.tensor([g, i])
 
     def group_targets(self, targets):
-        """-> per group {"bbox3d", "labels"} with labels renumbered inside the group (:268-297)."""
+        """seperate_targets_and_update_labels (:268-297) -> per group {"bbox3d", "labels"}: the group's boxes in class
+        order (one nonzero per class, concatenated) with labels renumbered inside the group."""
         out = []
         for classes in self.grouped_classes:
             lab = targets["labels"]
@@ -60,9 +67,21 @@ class SeperateClassifier(object):
             out.append({"bbox3d": targets["bbox3d"][sel], "labels": new})
         return out
 
+    def seperate_pred_logits(self, class_logits, sep_ids_g):
+        """:222-229: rows of group g (sep_ids_g[g]) restricted to the group's columns."""
+        assert class_logits.shape[1] == self.total_classes
+        return [class_logits[ids][:, torch.tensor(cols, device=class_logits.device)]
+                for ids, cols in zip(sep_ids_g, self.grouped_classes)]
+
+    def seperate_pred_box(self, box_regression, sep_ids_g):
+        """:231-239: the 7-column blocks of the group's classes."""
+        n = box_regression.shape[0]
+        assert box_regression.shape[1] == self.total_classes * 7
+        return [box_regression.view(n, -1, 7)[:, torch.tensor(cols, device=box_regression.device), :].reshape(n, -1)[ids]
+                for ids, cols in zip(sep_ids_g, self.grouped_classes)]
+
     def org_label(self, gi, group_labels):
-        lut = torch.tensor(self.grouped_classes[gi], dtype=torch.int64, device=group_labels.device)
-        return lut[group_labels]
+        return self.sep_labels_to_org_labels[gi].to(group_labels.device)[group_labels]
 
 
 def build_backbone(cfg):

@@ -17,6 +17,7 @@ from .._lib import check, ints, lib, ptr, require_gpu, stream_of
 
 _ARENA_BYTES = int(os.environ.get("D3D_ARENA_MB", "3072")) << 20   # 2/3 geometry lane + 1/3 feature lane
 _POOL = []          # recycled native metadata handles (one HBM arena each)
+_POOL_MAX = int(os.environ.get("D3D_ARENA_POOL", "8"))   # idle arenas kept (3 GiB each by default)
 _POOL_LOCK = threading.RLock()   # re-entrant: __del__ may run inside a locked region (GC)
 _SCRATCH = {}       # scratch tensors per (device, stream): buildings in flight on different streams never share one
 
@@ -171,14 +172,18 @@ class Metadata_3(object):
         self._h, self._bytes = h, key_bytes
 
     def __del__(self):
+        # at interpreter shutdown module globals (and _lib's library handle) may already be gone: then the process is
+        # about to release the arena anyway
         h = getattr(self, "_h", None)
-        if h is not None and _lib._lib is not None:
-            with _POOL_LOCK:
-                _POOL.append((self._home, self._bytes, h))
-                old = _POOL.pop(0) if len(_POOL) > 8 else None      # evict the oldest (its stream may be gone)
-            if old is not None:
-                _lib._lib.d3d_meta_destroy(old[2])
-            self._h = None
+        native = getattr(_lib, "_lib", None) if _lib is not None else None
+        if h is None or native is None or _POOL is None or _POOL_LOCK is None:
+            return
+        self._h = None
+        with _POOL_LOCK:
+            _POOL.append((self._home, self._bytes, h))
+            old = _POOL.pop(0) if len(_POOL) > _POOL_MAX else None      # evict the oldest (its stream may be gone)
+        if old is not None:
+            native.d3d_meta_destroy(old[2])
 
     def clear(self):
         check(lib().d3d_meta_clear(self._h))

@@ -196,16 +196,18 @@ class WarmupMultiStepLR(torch.optim.lr_scheduler._LRScheduler):
             if self.warmup_method == "constant":
                 f = self.warmup_factor
             else:
-                alpha = float(self.last_epoch) / max(self.warmup_iters, 1)
+                alpha = self.last_epoch / self.warmup_iters
                 f = self.warmup_factor * (1 - alpha) + alpha
         return [b * f * self.gamma ** bisect_right(self.milestones, self.last_epoch) for b in self.base_lrs]
 
 
 def make_lr_scheduler(cfg, optimizer, examples_per_epoch):
-    """solver/build.py:23-35: epochs -> iterations with INPUT.Example_num."""
-    it_per_epoch = max(1, examples_per_epoch // cfg.SOLVER.IMS_PER_BATCH)
-    return WarmupMultiStepLR(optimizer, [int(e * it_per_epoch) for e in cfg.SOLVER.LR_STEP_EPOCHS], cfg.SOLVER.GAMMA,
-                             cfg.SOLVER.WARMUP_FACTOR, int(cfg.SOLVER.WARMUP_EPOCHS * it_per_epoch),
+    """solver/build.py:23-35: epochs -> iterations with INPUT.Example_num (= examples_per_epoch, set by the data
+    loader in the reference); true division before int(), warm-up capped at 500 iterations (:27)."""
+    per = examples_per_epoch / cfg.SOLVER.IMS_PER_BATCH
+    steps = [int(e * per) for e in cfg.SOLVER.LR_STEP_EPOCHS]
+    warmup = min(int(cfg.SOLVER.WARMUP_EPOCHS * per), 500)
+    return WarmupMultiStepLR(optimizer, steps, cfg.SOLVER.GAMMA, cfg.SOLVER.WARMUP_FACTOR, warmup,
                              cfg.SOLVER.WARMUP_METHOD)
 
 

@@ -226,10 +226,11 @@ int d3d_sparse_to_dense_forward(d3d_meta *m, const int *spatial_size_host, const
 /* Pooler pre-processing in one launch: convert_metric_to_pixel (roi_box_feature_extractors.py:100), BoxList3D
  * yx_zb -> standard + convert_to_roi_format (modeling/poolers_3d.py:107-124, structures/bounding_box_3d.py:221-242)
  * and LevelMapper (poolers_3d.py:19-54 in its sqrt(max size)/canonical form).  boxes_metric [n,7] yx_zb in metres ->
- * rois [n,8] (batch 0, x, y, z centre, x, y, z size in full-resolution pixels, yaw in degrees) and, for
- * n_levels > 1, levels[n] = argmin_l |scales[l] - sqrt(max(size_y, size_x)) / canonical_size| (first minimum). */
+ * rois [n,8] (example index, x, y, z centre, x, y, z size in full-resolution pixels, yaw in degrees) and, for
+ * n_levels > 1, levels[n] = argmin_l |scales[l] - sqrt(max(size_y, size_x)) / canonical_size| (first minimum).
+ * batch_ids [n] (device, may be NULL = example 0): the example each box belongs to (poolers_3d.py:112-118).      */
 int d3d_roi_prepare(const float *boxes_metric, int n, float voxel_scale, const float *scales_host, int n_levels,
-                    float canonical_size, float *rois, int32_t *levels, void *stream);
+                    float canonical_size, const int32_t *batch_ids, float *rois, int32_t *levels, void *stream);
 /* a21. _C.roi_align_rotated_3d_forward (maskrcnn_benchmark/csrc/ROIAlignRotated3D.h:10-26;
  * csrc/cuda/ROIAlignRotated3D_cuda.cu:89-177).  Dense input [B,C,H,W,Z]; rois [K,8].          */
 int d3d_roi_align_rotated_3d_forward(const float *input, int B, int C, int H, int W, int Z,

@@ -29,7 +29,7 @@ def _sparse_input(dev, cin, seed=4, n_points=6000, size=(64, 64, 16)):
     return t, ft, x, sop, loc
 
 
-@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (64, 128), (128, 128), (256, 128), (128, 256)])
+@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (256, 128), (128, 256), (256, 256)])
 def test_conv_backward(dev, cin, cout):
     from detection_3d_amd import sparseconvnet as scn
     t, ft, x, sop, loc = _sparse_input(dev, cin)

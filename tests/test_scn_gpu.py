@@ -109,7 +109,8 @@ def test_rulebooks_exact(dev):
     assert np.array_equal(got, canon_rules(ru))
 
 
-@pytest.mark.parametrize("cin,cout", [(9, 32), (32, 32), (64, 64), (64, 128), (128, 128), (256, 128), (128, 256)])
+@pytest.mark.parametrize("cin,cout", [(9, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (256, 128), (128, 256),
+                                      (256, 256)])
 def test_conv_ops(dev, cin, cout):
     from detection_3d_amd import sparseconvnet as scn
     size = (64, 64, 16)
