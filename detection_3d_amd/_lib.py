@@ -114,6 +114,19 @@ _SIGS = {
     "d3d_nms_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "d3d_box_decode": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.c_float,
                                       vp, vp]),
+    # storage-type aware forms (d3d_dtype: 0 fp32, 1 bf16)
+    "d3d_packed_weight_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "d3d_pack_conv_weight_dt": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp]),
+    "d3d_subm_conv_forward_dt": (ctypes.c_int, [vp, c_int_p, c_int_p, vp, ctypes.c_int, vp, ctypes.c_int, vp, vp,
+                                                ctypes.c_int, vp, ctypes.POINTER(ctypes.c_double), bn_p]),
+    "d3d_conv_forward_dt": (ctypes.c_int, [vp, c_int_p, c_int_p, c_int_p, c_int_p, vp, ctypes.c_int, vp, ctypes.c_int,
+                                           vp, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_double), bn_p]),
+    "d3d_deconv_forward_dt": (ctypes.c_int, [vp, c_int_p, c_int_p, c_int_p, c_int_p, vp, ctypes.c_int, vp, ctypes.c_int,
+                                             vp, vp, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_double), bn_p]),
+    "d3d_bn_batch_invstd_dt": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, vp, vp, vp,
+                                              ctypes.c_size_t, ctypes.c_int, vp]),
+    "d3d_bn_apply_dt": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_float,
+                                       ctypes.c_int, vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS.keys())

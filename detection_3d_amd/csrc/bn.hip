@@ -41,6 +41,29 @@ __device__ __forceinline__ void stat_reduce_rows(const double *__restrict__ src,
   }
 }
 
+// 4 consecutive channels of a row as fp32: fp32 storage (16-byte load) or bf16 storage (8-byte load)
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ f32x4_t load4(const T *p);
+template <>
+__device__ __forceinline__ f32x4_t load4<float>(const float *p) {
+  return *(const f32x4_t *)p;
+}
+template <>
+__device__ __forceinline__ f32x4_t load4<unsigned short>(const unsigned short *p) {
+  const uint2 v = *(const uint2 *)p;
+  return f32x4_t{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                 __uint_as_float(v.y & 0xffff0000u)};
+}
+__device__ __forceinline__ void store4(float *p, f32x4_t v) { *(f32x4_t *)p = v; }
+__device__ __forceinline__ void store4(unsigned short *p, f32x4_t v) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  bf16x4 b;
+#pragma unroll
+  for (int j = 0; j < 4; j++) b[j] = (__bf16)v[j];   // round to nearest even
+  *(uint2 *)p = __builtin_bit_cast(uint2, b);
+}
+
 // Column statistics in ONE launch.  Workgroup b sums slice b of the rows in fp64 (threads = float4 channel
 // groups x concurrent rows, 4 rows in flight per thread) and parks sum / sum-of-squares in partial[b]; the
 // last workgroup of each group of kStatGroup slices to arrive (ticket counter) adds that group's partials,
@@ -50,7 +73,8 @@ __device__ __forceinline__ void stat_reduce_rows(const double *__restrict__ src,
 //   mode 1: train -> save_mean, save_invstd (biased), running update (BatchNormalization.cpp:20-38)
 //   mode 2: mean, powf(unbiased var + eps, -0.5)   (eval with batch statistics)
 // HBM-bound: rows * C * 4 bytes read once.  The tickets are zero on entry and are left zero.
-__global__ __launch_bounds__(kStatThreads) void k_bn_stats(const float *__restrict__ x, int rows, int C,
+template <typename T>
+__global__ __launch_bounds__(kStatThreads) void k_bn_stats(const T *__restrict__ x, int rows, int C,
                                                            unsigned int *tickets, double *partial, double *gpartial,
                                                            double *total, int mode, float *o0, float *o1,
                                                            float *running_mean, float *running_var, float eps,
@@ -72,7 +96,7 @@ __global__ __launch_bounds__(kStatThreads) void k_bn_stats(const float *__restri
     for (; r + 3 * RL < r1; r += 4 * RL) {
       f32x4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) v[u] = *(const f32x4 *)(x + (size_t)(r + u * RL) * C + g4 * 4);
+      for (int u = 0; u < 4; u++) v[u] = load4<T>(x + (size_t)(r + u * RL) * C + g4 * 4);
 #pragma unroll
       for (int u = 0; u < 4; u++)
 #pragma unroll
@@ -87,7 +111,7 @@ __global__ __launch_bounds__(kStatThreads) void k_bn_stats(const float *__restri
 #pragma unroll
       for (int u = 0; u < 3; u++) {
         const int rr = r + u * RL;
-        v[u] = rr < r1 ? *(const f32x4 *)(x + (size_t)rr * C + g4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        v[u] = rr < r1 ? load4<T>(x + (size_t)rr * C + g4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int u = 0; u < 3; u++)
@@ -195,7 +219,8 @@ __global__ void k_bn_eval_stats(const float *running_mean, const float *running_
 // A thread keeps ONE group of 4 channels and walks rows (grid-stride), so w and b are formed once per thread: with one
 // float4 per thread the four parameter vectors are 4x the L1 traffic of the payload (measured ~1 TB/s).
 // C4 = C / 4 divides the 256 threads of a workgroup (C in 4 .. 1024, powers of two).
-__global__ __launch_bounds__(256) void k_bn_apply_rows(const float *__restrict__ x, float *__restrict__ y, int rows,
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_apply_rows(const T *__restrict__ x, T *__restrict__ y, int rows,
                                                        int C, const float *__restrict__ save_mean,
                                                        const float *__restrict__ save_invstd,
                                                        const float *__restrict__ weight,
@@ -214,12 +239,11 @@ __global__ __launch_bounds__(256) void k_bn_apply_rows(const float *__restrict__
   for (; r + 3 * step < (size_t)rows; r += 4 * step) {   // 4 independent rows in flight
     d3d_f32x4 v[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) v[u] = *(const d3d_f32x4 *)(x + (r + u * step) * C + c);
+    for (int u = 0; u < 4; u++) v[u] = load4<T>(x + (r + u * step) * C + c);
 #pragma unroll
-    for (int u = 0; u < 4; u++) *(d3d_f32x4 *)(y + (r + u * step) * C + c) = bn_act(v[u], w, b, leakiness);
+    for (int u = 0; u < 4; u++) store4(y + (r + u * step) * C + c, bn_act(v[u], w, b, leakiness));
   }
-  for (; r < (size_t)rows; r += step)
-    *(d3d_f32x4 *)(y + r * C + c) = bn_act(*(const d3d_f32x4 *)(x + r * C + c), w, b, leakiness);
+  for (; r < (size_t)rows; r += step) store4(y + r * C + c, bn_act(load4<T>(x + r * C + c), w, b, leakiness));
 }
 
 // any other channel count
@@ -260,8 +284,8 @@ static void launch_bn_apply(const float *in, float *out, int rows, int planes, c
     const int rpi = 256 / C4;
     const long need = ((long)rows + rpi - 1) / rpi;
     const unsigned blocks = (unsigned)std::max<long>(1, std::min<long>(need, 256 * 8));
-    hipLaunchKernelGGL(k_bn_apply_rows, dim3(blocks), dim3(256), 0, s, in, out, rows, planes, mean, invstd, weight, bias,
-                       leakiness);
+    hipLaunchKernelGGL(k_bn_apply_rows<float>, dim3(blocks), dim3(256), 0, s, in, out, rows, planes, mean, invstd, weight,
+                       bias, leakiness);
   } else {
     const size_t total = (size_t)rows * planes;
     hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)((total / 4 + 256) / 256)), dim3(256), 0, s, in, out, total, planes,
@@ -280,7 +304,8 @@ __global__ __launch_bounds__(256) void k_add(const float *__restrict__ a, const 
   }
 }
 
-static int run_stats(const float *in, int rows, int C, void *scratch, size_t scratch_bytes, hipStream_t s, int mode,
+template <typename T>
+static int run_stats(const T *in, int rows, int C, void *scratch, size_t scratch_bytes, hipStream_t s, int mode,
                      float *o0, float *o1, float *running_mean, float *running_var, float eps, float momentum) {
   D3D_REQUIRE(C > 0 && C <= 4096 && C % 4 == 0, "batch norm: planes=%d must be a multiple of 4, <= 4096", C);
   const int C4 = C / 4;
@@ -294,7 +319,7 @@ static int run_stats(const float *in, int rows, int C, void *scratch, size_t scr
   double *partial = (double *)((char *)scratch + kTicketBytes);
   double *gpartial = partial + (size_t)kStatBlocks * 2 * C;
   double *total = gpartial + (size_t)kStatMaxGroups * 2 * C;
-  hipLaunchKernelGGL(k_bn_stats, dim3(nblk), dim3(kStatThreads), 0, s, in, rows, C, (unsigned int *)scratch, partial,
+  hipLaunchKernelGGL(k_bn_stats<T>, dim3(nblk), dim3(kStatThreads), 0, s, in, rows, C, (unsigned int *)scratch, partial,
                      gpartial, total, mode, o0, o1, running_mean, running_var, eps, momentum);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
@@ -349,6 +374,35 @@ int d3d_bn_apply(const float *in, float *out, int rows, int planes, const float 
   if (rows == 0) return D3D_OK;
   D3D_REQUIRE(in && out && mean && invstd && planes > 0 && rows > 0, "bn_apply: bad arguments");
   launch_bn_apply(in, out, rows, planes, mean, invstd, weight, bias, leakiness, s);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+/* storage-type aware forms (d3d_dtype) of the two inference-side BatchNorm entry points */
+int d3d_bn_batch_invstd_dt(const void *in, int rows, int planes, float eps, float *mean, float *invstd, void *scratch,
+                           size_t scratch_bytes, int dtype, void *stream) {
+  if (dtype == D3D_F32)
+    return d3d_bn_batch_invstd((const float *)in, rows, planes, eps, mean, invstd, scratch, scratch_bytes, stream);
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(dtype == D3D_BF16 && in && mean && invstd && rows > 0, "bn_batch_invstd_dt: bad arguments");
+  return run_stats((const unsigned short *)in, rows, planes, scratch, scratch_bytes, s, 2, mean, invstd, nullptr, nullptr,
+                   eps, 0.f);
+}
+
+int d3d_bn_apply_dt(const void *in, void *out, int rows, int planes, const float *mean, const float *invstd,
+                    const float *weight, const float *bias, float leakiness, int dtype, void *stream) {
+  if (dtype == D3D_F32)
+    return d3d_bn_apply((const float *)in, (float *)out, rows, planes, mean, invstd, weight, bias, leakiness, stream);
+  hipStream_t s = (hipStream_t)stream;
+  if (rows == 0) return D3D_OK;
+  const int C4 = planes >> 2;
+  D3D_REQUIRE(dtype == D3D_BF16 && in && out && mean && invstd && (planes & 3) == 0 && C4 >= 1 && C4 <= 256 &&
+              256 % C4 == 0, "bn_apply_dt: bad arguments (planes=%d)", planes);
+  const int rpi = 256 / C4;
+  const long need = ((long)rows + rpi - 1) / rpi;
+  const unsigned blocks = (unsigned)std::max<long>(1, std::min<long>(need, 256 * 8));
+  hipLaunchKernelGGL(k_bn_apply_rows<unsigned short>, dim3(blocks), dim3(256), 0, s, (const unsigned short *)in,
+                     (unsigned short *)out, rows, planes, mean, invstd, weight, bias, leakiness);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }

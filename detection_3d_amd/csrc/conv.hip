@@ -18,11 +18,6 @@ namespace d3d {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct BnPre {  // fused BatchNorm(+leaky ReLU) prologue; mean == nullptr: none
-  const float *mean, *invstd, *weight, *bias;
-  float leak;
-};
-
 __device__ __forceinline__ void wave_lds_sync() {
   // LDS operations of one wave execute in issue order; this only stops the compiler from
   // moving LDS accesses of different lanes across the hand-off point.
@@ -332,6 +327,11 @@ static constexpr int kSplitTargetWaves = 4096;  // below this many waves the lau
 
 // d3d_conv_time_next: HIP events the next k_conv launch of this thread is bracketed with (measurement only)
 static thread_local hipEvent_t t_time_start = nullptr, t_time_stop = nullptr;
+void conv_timing_take(hipEvent_t *start, hipEvent_t *stop) {
+  *start = t_time_start;
+  *stop = t_time_stop;
+  t_time_start = t_time_stop = nullptr;
+}
 
 template <int CT, int NCT, int COUT, int NT, int BPW>
 static int launch_t(d3d_meta *m, const Plan &p, const float *in, int cin, const float *wp,
@@ -494,6 +494,68 @@ int d3d_deconv_forward(d3d_meta *m, const int *in_size, const int *out_size, con
     *macs_host = (double)nr * cin * cout;
   }
   return launch_conv(m, *p, in, cin, packed_w, cout, residual, out, s, bn);
+}
+
+// ---- storage-type aware forms (d3d_dtype): D3D_F32 forwards to the functions above, D3D_BF16 runs conv_bf16.hip.
+// For bf16, `cin` is the stored row width (16, 32, 64, 128 or 256 channels; narrower inputs are zero padded).
+int d3d_subm_conv_forward_dt(d3d_meta *m, const int *size, const int *filt, const void *in, int cin,
+                             const void *packed_w, int cout, const void *residual, void *out, int dtype, void *stream,
+                             double *macs_host, const d3d_bn_prologue *bn) {
+  if (dtype == D3D_F32)
+    return d3d_subm_conv_forward(m, size, filt, (const float *)in, cin, (const float *)packed_w, cout,
+                                 (const float *)residual, (float *)out, stream, macs_host, bn);
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(dtype == D3D_BF16 && m && size && filt, "subm_conv_forward_dt: bad arguments");
+  int rc = d3d_subm_prepare(m, size, filt, stream, nullptr);
+  if (rc) return rc;
+  Plan *p = const_cast<Plan *>(find_plan(m, 0, size, filt, nullptr));
+  if (macs_host) {
+    long nr;
+    rc = plan_rules(m, *p, s, &nr);
+    if (rc) return rc;
+    *macs_host = (double)nr * cin * cout;
+  }
+  return launch_conv_bf16(m, *p, in, cin, packed_w, cout, residual, out, s, bn);
+}
+
+int d3d_conv_forward_dt(d3d_meta *m, const int *in_size, const int *out_size, const int *filt, const int *stride,
+                        const void *in, int cin, const void *packed_w, int cout, void *out, int dtype, void *stream,
+                        double *macs_host, const d3d_bn_prologue *bn) {
+  if (dtype == D3D_F32)
+    return d3d_conv_forward(m, in_size, out_size, filt, stride, (const float *)in, cin, (const float *)packed_w, cout,
+                            (float *)out, stream, macs_host, bn);
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(dtype == D3D_BF16 && m && in_size && out_size && filt && stride, "conv_forward_dt: bad arguments");
+  int rc = d3d_conv_prepare(m, in_size, out_size, filt, stride, stream, nullptr, nullptr);
+  if (rc) return rc;
+  Plan *p = const_cast<Plan *>(find_plan(m, 1, in_size, filt, stride));
+  if (macs_host) {
+    long nr;
+    rc = plan_rules(m, *p, s, &nr);
+    if (rc) return rc;
+    *macs_host = (double)nr * cin * cout;
+  }
+  return launch_conv_bf16(m, *p, in, cin, packed_w, cout, nullptr, out, s, bn);
+}
+
+int d3d_deconv_forward_dt(d3d_meta *m, const int *in_size, const int *out_size, const int *filt, const int *stride,
+                          const void *in, int cin, const void *packed_w, int cout, const void *residual, void *out,
+                          int dtype, void *stream, double *macs_host, const d3d_bn_prologue *bn) {
+  if (dtype == D3D_F32)
+    return d3d_deconv_forward(m, in_size, out_size, filt, stride, (const float *)in, cin, (const float *)packed_w, cout,
+                              (const float *)residual, (float *)out, stream, macs_host, bn);
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(dtype == D3D_BF16 && m && in_size && out_size && filt && stride, "deconv_forward_dt: bad arguments");
+  const Plan *p = nullptr;
+  int rc = get_deconv_plan(m, out_size, filt, stride, s, &p);
+  if (rc) return rc;
+  if (macs_host) {
+    long nr;
+    rc = plan_rules(m, *const_cast<Plan *>(p), s, &nr);
+    if (rc) return rc;
+    *macs_host = (double)nr * cin * cout;
+  }
+  return launch_conv_bf16(m, *p, in, cin, packed_w, cout, residual, out, s, bn);
 }
 
 }  // extern "C"

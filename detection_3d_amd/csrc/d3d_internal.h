@@ -164,6 +164,14 @@ int ensure_point_lists(d3d_meta *m, hipStream_t s);
 Arena &lane_arena(d3d_meta *m, hipStream_t s);
 
 // conv.hip
+struct BnPre {  // fused BatchNorm(+leaky ReLU) prologue of a convolution; mean == nullptr: none
+  const float *mean, *invstd, *weight, *bias;
+  float leak;
+};
+void conv_timing_take(hipEvent_t *start, hipEvent_t *stop);   // events armed by d3d_conv_time_next (or nullptr), disarms
+// conv_bf16.hip
+int launch_conv_bf16(d3d_meta *m, const Plan &p, const void *in, int cin, const void *packed_w, int cout,
+                     const void *residual, void *out, hipStream_t s, const d3d_bn_prologue *bn);
 int launch_conv(d3d_meta *m, const Plan &p, const float *in, int cin, const float *packed_w, int cout,
                 const float *residual, float *out, hipStream_t s, const d3d_bn_prologue *bn = nullptr);
 

@@ -88,7 +88,7 @@ class ConvProfiler(object):
             self.macs[scene_key] = []
 
     def wants(self, kind, fv, cin, cout):
-        return self.learn or self.focus is None or (cin, cout) in self.focus
+        return self.learn or self.focus is None or any(k[:2] == (cin, cout) for k in self.focus)
 
     def begin(self, kind=None, fv=None, cin=None, cout=None):
         """Arms the library to bracket the k_conv launch of the convolution call that follows with two HIP events
@@ -99,7 +99,7 @@ class ConvProfiler(object):
         check(lib().d3d_conv_time_next(ctypes.c_void_p(pair[0].cuda_event), ctypes.c_void_p(pair[1].cuda_event)))
         return pair
 
-    def end(self, start, kind, fv, cin, cout, rows_in, rows_out, macs):
+    def end(self, start, kind, fv, cin, cout, rows_in, rows_out, macs, dt=0):
         if start is None:       # not a focused family: only keep the call index aligned
             self._idx += 1
             return
@@ -109,8 +109,10 @@ class ConvProfiler(object):
         macs = self.macs[self.scene_key][self._idx]
         self._idx += 1
         rules = macs / max(cin * cout, 1)
-        # FLOPs = 2*rules*Cin*Cout; compulsory bytes = 4*(rows_in*Cin + rows_out*Cout) + 8*rules
-        self.records.append(((cin, cout), 2.0 * macs, 4.0 * (rows_in * cin + rows_out * cout) + 8.0 * rules,
+        # FLOPs = 2*rules*Cin*Cout; compulsory bytes = esize*(rows_in*Cin + rows_out*Cout) + 8*rules
+        esize = 2.0 if dt == BF16 else 4.0
+        key = (cin, cout) if dt == F32 else (cin, cout, "bf16")
+        self.records.append((key, 2.0 * macs, esize * (rows_in * cin + rows_out * cout) + 8.0 * rules,
                              start[0], start[1]))
 
     def summary(self):
@@ -242,16 +244,45 @@ class Metadata_3(object):
         return trip[:n.value]
 
 
+F32, BF16 = 0, 1        # d3d_dtype
+
+
+def dtype_code(t):
+    """d3d_dtype of a feature tensor (fp32 or bf16 storage)."""
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise _lib.D3DError(f"unsupported feature dtype {t.dtype} (float32 or bfloat16)")
+
+
+def stored_planes(planes, dtype):
+    """Row width a tensor of `planes` channels is stored with: bf16 rows are 16 / 32 / 64 / 128 / 256 channels wide
+    (zero padded), fp32 rows are exact."""
+    if dtype == torch.bfloat16:
+        return next(c for c in (16, 32, 64, 128, 256) if planes <= c)
+    return planes
+
+
 def n_rulebook_bits():
     return 32
 
 
-def pack_weight(weight):
-    """[fv, 1, Cin, Cout] reference layout -> MFMA k-interleaved layout (device tensor)."""
+def pack_weight(weight, dtype=torch.float32):
+    """[fv, 1, Cin, Cout] reference layout (fp32 parameter) -> MFMA k-interleaved layout of the compute type
+    (device tensor; bf16: Cin zero padded to the stored row width)."""
     require_gpu(weight)
     fv, groups, cin, cout = weight.shape
     if groups != 1:
         raise _lib.D3DError("groups != 1 is not supported")
+    if dtype == torch.bfloat16:
+        nbytes = lib().d3d_packed_weight_bytes(fv, cin, cout, BF16)
+        if nbytes == 0:
+            raise _lib.D3DError(f"unsupported bf16 conv shape fv={fv} Cin={cin} Cout={cout}")
+        packed = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=weight.device)
+        check(lib().d3d_pack_conv_weight_dt(ptr(weight.detach().float().contiguous()), fv, cin, cout, ptr(packed), BF16,
+                                            stream_of()))
+        return packed
     n = lib().d3d_packed_weight_floats(fv, cin, cout)
     if n == 0:
         raise _lib.D3DError(f"unsupported conv shape fv={fv} Cin={cin} Cout={cout}")
@@ -319,8 +350,8 @@ def batch_mean_invstd(features, eps):
     invstd = torch.empty_like(mean)
     nbytes = lib().d3d_bn_scratch_bytes(planes)
     scratch = _bn_scratch(features.device, nbytes)
-    check(lib().d3d_bn_batch_invstd(ptr(features), rows, planes, float(eps), ptr(mean), ptr(invstd), ptr(scratch),
-                                    scratch.numel(), stream_of()))
+    check(lib().d3d_bn_batch_invstd_dt(ptr(features), rows, planes, float(eps), ptr(mean), ptr(invstd), ptr(scratch),
+                                       scratch.numel(), dtype_code(features), stream_of()))
     return mean, invstd
 
 
@@ -329,16 +360,19 @@ def bn_apply(features, mean, invstd, weight, bias, leakiness):
     BatchNormalization_updateOutput (SCN/CPU/BatchNormalization.cpp:46-59)."""
     require_gpu(features)
     out = torch.empty_like(features)
-    check(lib().d3d_bn_apply(ptr(features), ptr(out), features.shape[0], features.shape[1], ptr(mean), ptr(invstd),
-                             ptr(weight), ptr(bias), float(leakiness), stream_of()))
+    check(lib().d3d_bn_apply_dt(ptr(features), ptr(out), features.shape[0], features.shape[1], ptr(mean), ptr(invstd),
+                                ptr(weight), ptr(bias), float(leakiness), dtype_code(features), stream_of()))
     return out
 
 
-def _conv_common(weight, packed):
+def _conv_common(weight, packed, feats):
+    """-> (filter volume, stored Cin of `feats`, Cout, packed weights of feats' dtype, d3d_dtype)"""
     fv, groups, cin, cout = weight.shape
-    if packed is None:
-        packed = pack_weight(weight)
-    return fv, cin, cout, packed
+    if packed is None or packed.dtype != feats.dtype:
+        packed = pack_weight(weight, feats.dtype)
+    if feats.shape[1] != stored_planes(cin, feats.dtype):
+        raise _lib.D3DError(f"convolution: features have {feats.shape[1]} channels, weight expects {cin}")
+    return fv, feats.shape[1], cout, packed, dtype_code(feats)
 
 
 def SubmanifoldConvolution_updateOutput(spatial_size, filter_size, m, input_features,
@@ -347,7 +381,7 @@ def SubmanifoldConvolution_updateOutput(spatial_size, filter_size, m, input_feat
     require_gpu(input_features, weight)
     if bias is not None and bias.numel():
         raise _lib.D3DError("bias is not supported (fpn_net.py builds every conv with bias=False)")
-    fv, cin, cout, packed = _conv_common(weight, packed)
+    fv, cin, cout, packed, dt = _conv_common(weight, packed, input_features)
     size, filt = _size3(spatial_size), _size3(filter_size)
     n = m.getNActive(size)
     output_features.resize_(n, cout)
@@ -356,11 +390,11 @@ def SubmanifoldConvolution_updateOutput(spatial_size, filter_size, m, input_feat
     want = ctypes.byref(macs) if ((prof is not None and prof.learn) or COUNT_MACS) else None
     if prof is not None:   # the library records the events around the k_conv launch itself (after any rulebook build)
         t0 = prof.begin("subm", fv, cin, cout)
-    check(lib().d3d_subm_conv_forward(m._h, ints(size), ints(filt), ptr(input_features), cin, ptr(packed),
-                                      cout, ptr(residual), ptr(output_features), stream_of(), want,
-                                      _bn_struct(bn)))
+    check(lib().d3d_subm_conv_forward_dt(m._h, ints(size), ints(filt), ptr(input_features), cin, ptr(packed),
+                                         cout, ptr(residual), ptr(output_features), dt, stream_of(), want,
+                                         _bn_struct(bn)))
     if prof is not None:
-        prof.end(t0, "subm", fv, cin, cout, n, n, macs.value)
+        prof.end(t0, "subm", fv, cin, cout, n, n, macs.value, dt)
     return macs.value
 
 
@@ -394,7 +428,7 @@ def Convolution_updateOutput(input_size, output_size, filter_size, filter_stride
     require_gpu(input_features, weight)
     if bias is not None and bias.numel():
         raise _lib.D3DError("bias is not supported")
-    fv, cin, cout, packed = _conv_common(weight, packed)
+    fv, cin, cout, packed, dt = _conv_common(weight, packed, input_features)
     isz, osz, filt, st = _size3(input_size), _size3(output_size), _size3(filter_size), _size3(filter_stride)
     n_out = ctypes.c_int(0)
     check(lib().d3d_conv_prepare(m._h, ints(isz), ints(osz), ints(filt), ints(st), stream_of(),
@@ -405,10 +439,10 @@ def Convolution_updateOutput(input_size, output_size, filter_size, filter_stride
     want = ctypes.byref(macs) if ((prof is not None and prof.learn) or COUNT_MACS) else None
     if prof is not None:
         t0 = prof.begin("conv", fv, cin, cout)
-    check(lib().d3d_conv_forward(m._h, ints(isz), ints(osz), ints(filt), ints(st), ptr(input_features), cin,
-                                 ptr(packed), cout, ptr(output_features), stream_of(), want, _bn_struct(bn)))
+    check(lib().d3d_conv_forward_dt(m._h, ints(isz), ints(osz), ints(filt), ints(st), ptr(input_features), cin,
+                                    ptr(packed), cout, ptr(output_features), dt, stream_of(), want, _bn_struct(bn)))
     if prof is not None:
-        prof.end(t0, "conv", fv, cin, cout, input_features.shape[0], n_out.value, macs.value)
+        prof.end(t0, "conv", fv, cin, cout, input_features.shape[0], n_out.value, macs.value, dt)
     return macs.value
 
 
@@ -418,7 +452,7 @@ def Deconvolution_updateOutput(input_size, output_size, filter_size, filter_stri
     require_gpu(input_features, weight)
     if bias is not None and bias.numel():
         raise _lib.D3DError("bias is not supported")
-    fv, cin, cout, packed = _conv_common(weight, packed)
+    fv, cin, cout, packed, dt = _conv_common(weight, packed, input_features)
     isz, osz, filt, st = _size3(input_size), _size3(output_size), _size3(filter_size), _size3(filter_stride)
     n = m.getNActive(osz)
     output_features.resize_(n, cout)
@@ -427,11 +461,11 @@ def Deconvolution_updateOutput(input_size, output_size, filter_size, filter_stri
     want = ctypes.byref(macs) if ((prof is not None and prof.learn) or COUNT_MACS) else None
     if prof is not None:
         t0 = prof.begin("deconv", fv, cin, cout)
-    check(lib().d3d_deconv_forward(m._h, ints(isz), ints(osz), ints(filt), ints(st), ptr(input_features),
-                                   cin, ptr(packed), cout, ptr(residual), ptr(output_features), stream_of(),
-                                   want, _bn_struct(bn)))
+    check(lib().d3d_deconv_forward_dt(m._h, ints(isz), ints(osz), ints(filt), ints(st), ptr(input_features),
+                                      cin, ptr(packed), cout, ptr(residual), ptr(output_features), dt, stream_of(),
+                                      want, _bn_struct(bn)))
     if prof is not None:
-        prof.end(t0, "deconv", fv, cin, cout, input_features.shape[0], n, macs.value)
+        prof.end(t0, "deconv", fv, cin, cout, input_features.shape[0], n, macs.value, dt)
     return macs.value
 
 

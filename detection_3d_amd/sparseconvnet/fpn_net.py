@@ -48,6 +48,9 @@ class FPN_Net(torch.nn.Module):
         self.residual_blocks = residual_blocks
         self.reps = reps
         self.fuse_adds, self.skip_unused = fuse_adds, skip_unused
+        # storage type of the feature maps between the input layer and the maps handed to RPN / pooler (inference):
+        # torch.bfloat16 = BASELINE.json configs[4] (bf16 rows and weights, fp32 accumulation, fp32 statistics)
+        self.compute_dtype = torch.float32
         n_scales = len(nPlanesF)
         assert len(self.down_kernels) == n_scales - 1 == len(self.down_strides)
         in_channels = sum({'xyz': 3, 'color': 3, 'normal': 3}[e] for e in raw_elements)
@@ -104,10 +107,25 @@ class FPN_Net(torch.nn.Module):
             self.m_mergeds.append(scn.SubmanifoldConvolution(dimension, nPlaneM, nPlaneM, 3, False))
 
     # ------------------------------------------------------------------------------------
+    def _to_compute(self, net):
+        """input-layer output (fp32 [n, 9]) -> storage type of the backbone: bf16 rows are padded to 16 channels"""
+        if self.compute_dtype == torch.float32:
+            return net
+        assert not torch.is_grad_enabled() or not net.features.requires_grad, "bf16 storage is an inference path"
+        f = net.features
+        width = scn.SCN.stored_planes(f.shape[1], self.compute_dtype)
+        net.features = torch.nn.functional.pad(f, (0, width - f.shape[1])).to(self.compute_dtype)
+        return net
+
+    def _from_compute(self, maps):
+        if self.compute_dtype == torch.float32:
+            return maps
+        return [None if t is None else scn.SparseConvNetTensor(t.features.float(), t.metadata, t.spatial_size) for t in maps]
+
     def forward(self, net0):
         if TWO_LANE and _is_gpu_input(net0):
             return self._forward_two_lane(net0)
-        net1 = self.layers_in(net0)
+        net1 = self.layers_in[1](self._to_compute(self.layers_in[0](net0)))
         return self.forward_fpn(net1)
 
     def _forward_two_lane(self, net0):
@@ -157,7 +175,7 @@ class FPN_Net(torch.nn.Module):
 
         try:
             lane(0)
-            net = self.layers_in[1](net)
+            net = self.layers_in[1](self._to_compute(net))
             out = self.forward_fpn(net, prepared=True, lane=lane)
         finally:
             main.wait_stream(geo)
@@ -233,7 +251,7 @@ class FPN_Net(torch.nn.Module):
 
     def stage_features(self, net):
         """Stage 2: the feature pass over the prepared geometry (no host synchronisation)."""
-        return self.forward_fpn(self.layers_in[1](net), prepared=True)
+        return self.forward_fpn(self.layers_in[1](self._to_compute(net)), prepared=True)
 
     def forward_fpn(self, net, prepared=False, lane=None):
         n_scales = len(self.m_downs)
@@ -266,4 +284,4 @@ class FPN_Net(torch.nn.Module):
         roi_maps = [ups[i] for i in self.roi_scales_from_top]
         for i in range(len(rpn_maps_3d)):
             assert rpn_maps_3d[i].spatial_size.tolist() == [int(v) for v in self.rpn_map_sizes[i]]
-        return rpn_maps, roi_maps
+        return self._from_compute(rpn_maps), self._from_compute(roi_maps)

@@ -205,13 +205,17 @@ class _SparseToDenseFn(torch.autograd.Function):
 class _PackedWeightMixin(object):
     """Caches the MFMA-layout copy of `weight` until the parameter changes."""
 
-    def _packed(self):
+    def _packed(self, dtype=torch.float32):
+        """packed copy of the (fp32) parameter in the layout / storage type of the features it will meet"""
         w = self.weight
         tag = (w._version, w.data_ptr(), w.device)
         if getattr(self, "_packed_tag", None) != tag:
-            self._packed_w = SCN.pack_weight(w)
+            self._packed_w = {}
             self._packed_tag = tag
-        return self._packed_w
+        p = self._packed_w.get(dtype)
+        if p is None:
+            p = self._packed_w[dtype] = SCN.pack_weight(w, dtype)
+        return p
 
 
 class InputLayer(Module):
@@ -250,10 +254,10 @@ class SubmanifoldConvolution(Module, _PackedWeightMixin):
 
     def forward(self, input, residual=None):
         feats, bn = _conv_input(input)
-        assert feats.nelement() == 0 or feats.size(1) == self.nIn, (self.nIn, self.nOut)
+        assert feats.nelement() == 0 or feats.size(1) == SCN.stored_planes(self.nIn, feats.dtype), (self.nIn, self.nOut)
         f = _apply(_ConvFn, feats, self.weight, None if residual is None else residual.features, 0,
                           input.metadata, input.spatial_size, input.spatial_size, self.filter_size, None,
-                          self._packed(), bn)
+                          self._packed(feats.dtype), bn)
         return SparseConvNetTensor(f, input.metadata, input.spatial_size)
 
     def input_spatial_size(self, out_size):
@@ -275,12 +279,12 @@ class Convolution(Module, _PackedWeightMixin):
 
     def forward(self, input):
         feats, bn = _conv_input(input)
-        assert feats.nelement() == 0 or feats.size(1) == self.nIn
+        assert feats.nelement() == 0 or feats.size(1) == SCN.stored_planes(self.nIn, feats.dtype)
         out_size = (input.spatial_size - self.filter_size) // self.filter_stride + 1
         assert ((out_size - 1) * self.filter_stride + self.filter_size == input.spatial_size).all(), \
             (input.spatial_size, out_size, self.filter_size, self.filter_stride)
         f = _apply(_ConvFn, feats, self.weight, None, 1, input.metadata, input.spatial_size, out_size,
-                          self.filter_size, self.filter_stride, self._packed(), bn)
+                          self.filter_size, self.filter_stride, self._packed(feats.dtype), bn)
         return SparseConvNetTensor(f, input.metadata, out_size)
 
     def input_spatial_size(self, out_size):
@@ -302,11 +306,11 @@ class Deconvolution(Module, _PackedWeightMixin):
 
     def forward(self, input, residual=None):
         feats, bn = _conv_input(input)
-        assert feats.nelement() == 0 or feats.size(1) == self.nIn
+        assert feats.nelement() == 0 or feats.size(1) == SCN.stored_planes(self.nIn, feats.dtype)
         out_size = (input.spatial_size - 1) * self.filter_stride + self.filter_size
         f = _apply(_ConvFn, feats, self.weight, None if residual is None else residual.features, 2,
                           input.metadata, input.spatial_size, out_size, self.filter_size, self.filter_stride,
-                          self._packed(), bn)
+                          self._packed(feats.dtype), bn)
         return SparseConvNetTensor(f, input.metadata, out_size)
 
     def input_spatial_size(self, out_size):
@@ -337,6 +341,10 @@ class BatchNormalization(Module):
             return _PendingBN(f, (mean, invstd, self.weight if self.affine else None,
                                   self.bias if self.affine else None, self.leakiness), input.metadata,
                               input.spatial_size)
+        if f.dtype != torch.float32:    # bf16 storage: inference with batch statistics only (the deferred form below)
+            mean, invstd = SCN.batch_mean_invstd(f, self.eps)
+            return _like(input, SCN.bn_apply(f, mean, invstd, self.weight if self.affine else None,
+                                             self.bias if self.affine else None, self.leakiness))
         if self.training or self.track_running_stats:
             mean, var = self.running_mean, self.running_var
         else:  # batchNormalization.py:53-55: batch statistics stand in for the running ones
@@ -404,6 +412,9 @@ def add_feature_planes(inputs):
             acc = acc + other.features
         return _like(inputs[0], acc)
     for other in inputs[1:]:
+        if acc.dtype != torch.float32:          # bf16 storage: fp32 sum, one rounding
+            acc = (acc.float() + other.features.float()).to(acc.dtype)
+            continue
         out = torch.empty_like(acc)
         check(lib().d3d_add(ptr(acc), ptr(other.features.contiguous()), ptr(out), acc.numel(), stream_of()))
         acc = out

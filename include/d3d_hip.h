@@ -150,6 +150,31 @@ int d3d_deconv_forward(d3d_meta *m, const int *in_size_host, const int *out_size
                        const float *packed_w, int cout, const float *residual, float *out,
                        void *stream, double *macs_host, const d3d_bn_prologue *bn_host);
 
+/* ---- bf16 storage (BASELINE.json configs[4]; the reference dispatches on the tensor type in
+ * SCN/CUDA/Convolution.cu:444-521 and sparseconvnet_cuda.cpp).  Feature rows, packed weights and outputs are bf16
+ * (raw 16-bit words), accumulation is fp32 on v_mfma_f32_32x32x16_bf16, BatchNorm statistics stay fp64/fp32.
+ * For D3D_BF16 `cin` is the STORED row width: 16, 32, 64, 128 or 256 channels (narrower inputs are zero padded by
+ * the caller; d3d_pack_conv_weight_dt pads the weights to match).  D3D_F32 forwards to the fp32 entry points.      */
+typedef enum { D3D_F32 = 0, D3D_BF16 = 1 } d3d_dtype;
+size_t d3d_packed_weight_bytes(int filter_volume, int cin, int cout, int dtype);
+int d3d_pack_conv_weight_dt(const float *w, int filter_volume, int cin, int cout, void *packed, int dtype,
+                            void *stream);
+int d3d_subm_conv_forward_dt(d3d_meta *m, const int *spatial_size_host, const int *filter_host, const void *in,
+                             int cin, const void *packed_w, int cout, const void *residual, void *out, int dtype,
+                             void *stream, double *macs_host, const d3d_bn_prologue *bn_host);
+int d3d_conv_forward_dt(d3d_meta *m, const int *in_size_host, const int *out_size_host, const int *filter_host,
+                        const int *stride_host, const void *in, int cin, const void *packed_w, int cout, void *out,
+                        int dtype, void *stream, double *macs_host, const d3d_bn_prologue *bn_host);
+int d3d_deconv_forward_dt(d3d_meta *m, const int *in_size_host, const int *out_size_host, const int *filter_host,
+                          const int *stride_host, const void *in, int cin, const void *packed_w, int cout,
+                          const void *residual, void *out, int dtype, void *stream, double *macs_host,
+                          const d3d_bn_prologue *bn_host);
+/* d3d_bn_batch_invstd / d3d_bn_apply on a tensor of the given storage type (statistics and parameters fp32). */
+int d3d_bn_batch_invstd_dt(const void *in, int rows, int planes, float eps, float *mean, float *invstd,
+                           void *scratch, size_t scratch_bytes, int dtype, void *stream);
+int d3d_bn_apply_dt(const void *in, void *out, int rows, int planes, const float *mean, const float *invstd,
+                    const float *weight, const float *bias, float leakiness, int dtype, void *stream);
+
 /* a7. Backward (training).  SubmanifoldConvolution_backward / Convolution_backward / Deconvolution_backward
  * (SCN/sparseconvnet.h:92-98,106-111,153-158; SCN/CUDA/Convolution.cu:249-442): d_in is overwritten,
  * d_weight [fv, Cin, Cout] is accumulated into (the caller pre-zeroes it, as the reference's Python does).
