@@ -213,14 +213,65 @@ class RPNModule(nn.Module):
                                         flag='rpn_post')                        # scores_k is sorted: no re-sort
         return proposals[keep], scores_k[keep]
 
-    def forward(self, features_sparse, targets=None):
+    @torch.no_grad()
+    def select_proposals_segments(self, objectness, box_regression, anchors, example, n_examples, train):
+        """RPNPostProcessor.forward_for_single_feature_map (rpn/inference_3d.py:82-163) for every (example, class group)
+        pair at once: objectness [n, G], box_regression [n, 7 G], anchors [n, 7], example int64 [n] (None: one example).
+        Segment s = example * G + group gets its own top-k (the other examples' anchors are masked out), one decode
+        launch and one batched NMS serve all segments, ONE read-back returns the survivor counts.
+        -> list over segments of (proposals [m_s, 7], scores [m_s])."""
+        pre, post = self.top_n[bool(train)]
+        n, G = objectness.shape
+        B = int(n_examples)
+        dev = objectness.device
+        scores = objectness.sigmoid().t()                                   # [G, n]
+        if B > 1:
+            member = example.view(1, -1) == torch.arange(B, device=dev).view(-1, 1)     # [B, n]
+            sc = torch.where(member[:, None, :], scores[None], scores.new_full((), -1.0)).reshape(B * G, n)
+            per_example = member.sum(1)
+        else:
+            sc = scores
+            per_example = torch.full((1,), n, dtype=torch.int64, device=dev)
+        S = B * G
+        k = min(pre, n)
+        sk, idx = sc.topk(k, dim=1, sorted=True)                            # [S, k]: inference_3d.py:109 per segment
+        counts = per_example.clamp(max=k).view(B, 1).expand(B, G).reshape(S).to(torch.int32).contiguous()
+        group_of = torch.arange(G, device=dev).repeat(B).view(S, 1)
+        reg = box_regression.view(n, G, 7)[idx, group_of]                   # [S, k, 7]
+        flat = idx.reshape(-1)
+        props = box_ops.box_decode(reg.reshape(-1, 7), anchors[flat])       # :123
+        order = torch.arange(S * k, dtype=torch.int32, device=dev).view(S, k)
+        keep, nk = box_ops.nms_3d_batched(props, order, counts, k, self.nms_thresh, self.nms_aug_thickness, post)
+        sk = sk.reshape(-1)
+        out = []
+        for s_, m in enumerate(nk.tolist()):                                # the one host synchronisation
+            sel = keep[s_, :m].long()
+            out.append((props[sel], sk[sel]))
+        return out
+
+    def forward(self, features_sparse, targets=None, n_examples=1):
         """eval: (proposals, objectness).  train: (proposals incl. GT boxes, objectness, loss dict)
-        (rpn_sparse3d.py:233-270, rpn/inference_3d.py:53-80,180-199)."""
+        (rpn_sparse3d.py:233-270, rpn/inference_3d.py:53-80,180-199).  n_examples > 1 (inference): returns
+        (proposals, objectness, sep_id or None, example_id) with the rows ordered by example (then class group)."""
         objectness, box_regression = self.head([f.features for f in features_sparse])
         with torch.no_grad():
             anchors = self.anchor_generator.forward_cat(features_sparse)
         assert objectness.shape[0] == box_regression.shape[0] == anchors.shape[0]
-        if self.sep.need_seperate and self.head.seperate_rpn > 1:
+        grouped = self.sep.need_seperate and self.head.seperate_rpn > 1
+        if n_examples > 1:
+            if self.training:
+                raise NotImplementedError("training with more than one example per batch is not built "
+                                          "(the reference's configs train with IMS_PER_BATCH 1)")
+            A = self.anchor_generator.num_anchors_per_location()
+            example = torch.cat([f.get_spatial_locations()[:, 3].repeat_interleave(A) for f in features_sparse])
+            segs = self.select_proposals_segments(objectness.detach(), box_regression.detach(), anchors, example,
+                                                  n_examples, False)
+            G = objectness.shape[1]
+            dev = anchors.device
+            sep_id = torch.cat([torch.full((p.shape[0],), i % G, dtype=torch.int64, device=dev) for i, (p, _) in enumerate(segs)])
+            ex_id = torch.cat([torch.full((p.shape[0],), i // G, dtype=torch.int64, device=dev) for i, (p, _) in enumerate(segs)])
+            return (torch.cat([p for p, _ in segs]), torch.cat([sc for _, sc in segs]), sep_id if grouped else None, ex_id)
+        if grouped:
             return self._forward_grouped(anchors, objectness, box_regression, targets)
         proposals, scores = self.select_proposals(objectness.detach(), box_regression.detach(), anchors,
                                                   self.training)
@@ -238,9 +289,12 @@ class RPNModule(nn.Module):
         and one loss pair per class group; proposals carry their group id (`sep_id`)."""
         props, scores, sep_ids, losses = [], [], [], {}
         tg = self.sep.group_targets(targets) if self.training else [None] * self.sep.group_num
+        # the groups' top-k / decode / NMS as segments of ONE launch set (seperate_rpn_selector loops the selector)
+        segs = self.select_proposals_segments(objectness.detach(), box_regression.detach(), anchors, None, 1,
+                                              self.training)
         for gi in range(self.sep.group_num):
             obj_g, reg_g = objectness[:, gi], box_regression[:, 7 * gi:7 * gi + 7]
-            p, sc = self.select_proposals(obj_g.detach(), reg_g.detach().contiguous(), anchors, self.training)
+            p, sc = segs[gi]
             if self.training:
                 gt = tg[gi]["bbox3d"]
                 if self.add_gt_proposals and gt.shape[0]:
@@ -284,12 +338,12 @@ class Pooler(nn.Module):
         dif = torch.abs(torch.tensor(self.scales, device=boxes.device)[None, :] - rate[:, None])
         return torch.argmin(dif, 1)
 
-    def pool_metric(self, x, boxes_metric, voxel_scale, channels_inner=True):
+    def pool_metric(self, x, boxes_metric, voxel_scale, channels_inner=True, batch_ids=None):
         """Inference: metric proposals -> pooled features with ONE pre-processing launch (pixels, RoI format and FPN
         level: d3d_roi_prepare, bit-identical to convert_to_roi_format / map_levels) and one launch per level that
         fills its RoIs' slots of the result in place (no nonzero / index_put, no host synchronisation)."""
         ph, pw, pz = self.output_size
-        rois, levels = roi_prepare(boxes_metric, voxel_scale, self.scales, self.canonical_size)
+        rois, levels = roi_prepare(boxes_metric, voxel_scale, self.scales, self.canonical_size, batch_ids)
         K, C = rois.shape[0], x[0].features.shape[1]
         out = torch.empty((K, ph, pw, C, pz) if channels_inner else (K, C, ph, pw, pz), dtype=torch.float32,
                           device=rois.device)
@@ -369,12 +423,12 @@ class FPN2MLPFeatureExtractor(nn.Module):
                               .contiguous())
         return self._fc6_rows[1]
 
-    def _forward_rows(self, x0, p):
+    def _forward_rows(self, x0, p, batch_ids=None):
         """Inference path without layout changes (p: metric proposals): the pooler writes [K, ph, pw, C, pz], whose rows feed the
         [1,1,pz] convolution as a GEMM; BatchNorm3d + ReLU is one row-wise BatchNorm over [K*ph*pw, rep]
         (batch statistics, biased variance: F.batch_norm in training mode), fc6 reads the rows in place."""
         conv, bn = self.conv3d[0], self.conv3d[1]
-        pooled = self.pooler.pool_metric(x0, p, self.voxel_scale, channels_inner=True)
+        pooled = self.pooler.pool_metric(x0, p, self.voxel_scale, channels_inner=True, batch_ids=batch_ids)
         K, ph, pw, C, pz = pooled.shape
         y = torch.addmm(conv.bias, pooled.view(K * ph * pw, C * pz), conv.weight.view(conv.out_channels, C * pz).t())
         rep = y.shape[1]
@@ -384,12 +438,16 @@ class FPN2MLPFeatureExtractor(nn.Module):
         h = torch.addmm(self.fc6.bias, out.view(K, ph * pw * rep), self._fc6_rows_weight(ph * pw).t())
         return F.relu(self.fc7(F.relu(h)))
 
-    def forward(self, x0, proposals):
+    def forward(self, x0, proposals, batch_ids=None):
+        """batch_ids: int32 [K] example of every proposal (inference with several examples per batch; the RoI op reads
+        the example's sites, poolers_3d.py:112-118); None = one example."""
         conv, bn = self.conv3d[0], self.conv3d[1]
         if (not torch.is_grad_enabled() and tuple(conv.kernel_size) == (1, 1, self.pooler.output_size[2])
                 and tuple(conv.stride) == (1, 1, 1) and (bn.training or not bn.track_running_stats)
                 and proposals.shape[0] > 0):
-            return self._forward_rows(x0, proposals)                            # metric boxes: pixels on the device
+            return self._forward_rows(x0, proposals, batch_ids)                 # metric boxes: pixels on the device
+        if batch_ids is not None:
+            raise NotImplementedError("several examples per batch: only the inference path of the box head is built")
         p = proposals.clone()
         p[:, 0:6] *= self.voxel_scale                                           # convert_metric_to_pixel
         x1 = self._head_conv(self.pooler(x0, p))
@@ -461,6 +519,65 @@ class PostProcessor(nn.Module):
         b, s, l = boxes.view(-1, 7)[flat], prob.reshape(-1)[flat], flat % nc
         return {"bbox3d": b, "scores": s, "labels": l}
 
+    @torch.no_grad()
+    def forward_segments(self, class_logits, box_regression, proposals, seg_id, seg_sizes, seg_group, grouped_classes):
+        """The post-processing of several (example, class group) row segments in ONE launch set: what
+        SeperateClassifier.post_processor (seperate_classifier.py:299-321) and the per-image loop of
+        box_head_3d/inference.py:66-99 do one call at a time.
+          class_logits [K, T], box_regression [K, 7 T]: all rows, all T = total class columns;
+          seg_id int64 [K]: segment of every row; seg_sizes: rows per segment (host list, for the NMS width);
+          seg_group[s]: class group of segment s; grouped_classes[g]: the group's columns, background first.
+        Every (segment, foreground class of its group) is one NMS segment; the top DETECTIONS_PER_IMG are taken per
+        segment.  -> list over segments of {"bbox3d", "scores", "labels" (inside the group)}."""
+        K, T = class_logits.shape
+        S, G = len(seg_sizes), len(grouped_classes)
+        dev = class_logits.device
+        empty = {"bbox3d": class_logits.new_zeros((0, 7)), "scores": class_logits.new_zeros((0,)),
+                 "labels": torch.zeros(0, dtype=torch.int64, device=dev)}
+        cmax = max(len(g) for g in grouped_classes)
+        if K == 0 or cmax < 2:
+            return [dict(empty) for _ in range(S)]
+        cols = torch.tensor([list(g) + [g[0]] * (cmax - len(g)) for g in grouped_classes], dtype=torch.int64, device=dev)
+        group_of_row = torch.tensor(list(seg_group), dtype=torch.int64, device=dev)[seg_id]              # [K]
+        # softmax over each group's own columns (the same row-wise op as the per-group call), then per row the
+        # probabilities of its group; padded class slots get probability 0
+        prob = class_logits.new_zeros((K, cmax))
+        for g, classes in enumerate(grouped_classes):
+            pg = F.softmax(class_logits[:, cols[g, :len(classes)]], -1)
+            prob[:, :len(classes)] = torch.where((group_of_row == g).view(-1, 1), pg, prob[:, :len(classes)])
+        c = cols[group_of_row]                                                                            # [K, cmax]
+        reg = box_regression.view(K, T, 7).gather(1, c[:, :, None].expand(-1, -1, 7)).reshape(K, cmax * 7)
+        boxes = box_ops.box_decode(reg, proposals, self.weights)                                          # [K, 7 cmax]
+        # NMS segments (s, j): rows of segment s with prob[:, j] > thresh, descending score, ties: lower row first
+        nseg = S * (cmax - 1)
+        member = seg_id.view(1, -1) == torch.arange(S, device=dev).view(-1, 1)                            # [S, K]
+        p = prob[:, 1:].t()                                                                               # [cmax-1, K]
+        cand = (p > self.score_thresh)[None] & member[:, None, :]                                         # [S, cmax-1, K]
+        sc = torch.where(cand, p[None], p.new_full((), -1.0)).reshape(nseg, K)
+        idx = torch.sort(sc, dim=1, descending=True, stable=True)[1]
+        n_max = max(1, min(max(seg_sizes), 2000))                                                         # pre_max_size
+        slot = (torch.arange(cmax - 1, device=dev) + 1).repeat(S).view(nseg, 1)
+        order = (idx[:, :n_max] * cmax + slot).to(torch.int32).contiguous()
+        counts = cand.reshape(nseg, K).sum(1).clamp(max=n_max).to(torch.int32)
+        keep, nk = box_ops.nms_3d_batched(boxes.view(-1, 7), order, counts, n_max, self.nms, self.nms_aug_thickness, 500)
+        valid = torch.arange(n_max, device=dev).view(1, -1) < nk.view(-1, 1)                              # [nseg, n_max]
+        flat = torch.where(valid, keep, torch.zeros_like(keep)).long()                                    # row * cmax + slot
+        s_all = torch.where(valid, prob.reshape(-1)[flat], prob.new_full((), -1.0)).view(S, -1)
+        valid, flat = valid.view(S, -1), flat.view(S, -1)
+        if 0 < self.detections_per_img < s_all.shape[1]:                                                 # :140-148 per segment
+            thresh = torch.topk(s_all, self.detections_per_img, dim=1, sorted=True)[0][:, -1]
+            sel = valid & (s_all >= thresh.view(-1, 1))
+        else:
+            sel = valid
+        n_sel = sel.sum(1).tolist()                                                                       # the one synchronisation
+        picked = flat[sel]                                                                                # segment-major
+        b, sc_, lab = boxes.view(-1, 7)[picked], prob.reshape(-1)[picked], picked % cmax
+        out, o = [], 0
+        for m in n_sel:
+            out.append({"bbox3d": b[o:o + m], "scores": sc_[o:o + m], "labels": lab[o:o + m]})
+            o += m
+        return out
+
     def _select_reference(self, prob, boxes):
         """The same selection spelled in tensor ops (what forward ran before the d3d_post_* launches; kept as the
         parity reference of tests/test_detector_gpu.py)."""
@@ -501,36 +618,63 @@ class ROIBoxHead3D(nn.Module):
         """seperate_subsample / roi_cross_entropy_seperated / roi_box_loss_seperated / post_processor
         (seperate_classifier.py:111-176,299-321)."""
         sep = self.sep
-        if self.training:
-            tg = sep.group_targets(targets)
-            ps, ls, rs, ids = [], [], [], []
-            for gi in range(sep.group_num):
-                p, l, r = self.loss_evaluator.subsample(proposals[sep_id == gi], tg[gi]["bbox3d"], tg[gi]["labels"])
-                ps.append(p); ls.append(l); rs.append(r)
-                ids.append(torch.full((p.shape[0],), gi, dtype=torch.int64, device=p.device))
-            proposals, labels, reg_targets, sep_id = torch.cat(ps), torch.cat(ls), torch.cat(rs), torch.cat(ids)
+        if not self.training:
+            return self._forward_eval_segments(roi_features, proposals, sep_id, None, 1)[0]
+        tg = sep.group_targets(targets)
+        ps, ls, rs, ids = [], [], [], []
+        for gi in range(sep.group_num):
+            p, l, r = self.loss_evaluator.subsample(proposals[sep_id == gi], tg[gi]["bbox3d"], tg[gi]["labels"])
+            ps.append(p); ls.append(l); rs.append(r)
+            ids.append(torch.full((p.shape[0],), gi, dtype=torch.int64, device=p.device))
+        proposals, labels, reg_targets, sep_id = torch.cat(ps), torch.cat(ls), torch.cat(rs), torch.cat(ids)
         x = self.feature_extractor(roi_features, proposals)
         logits, reg = self.predictor(x)
         assert logits.shape[1] == sep.total_classes
-        n = logits.shape[0]
-        out = {} if self.training else []
-        for gi in range(sep.group_num):
-            idx = torch.nonzero(sep_id == gi).view(-1)
-            cols = torch.tensor(sep.grouped_classes[gi], device=logits.device)
-            lg = logits[idx][:, cols]
-            rg = reg.view(n, -1, 7)[:, cols, :].reshape(n, -1)[idx]
-            if self.training:
-                c, b = self.loss_evaluator(lg, rg, proposals[idx], labels[idx], reg_targets[idx])
-                out[f"loss_classifier_roi_{gi}"], out[f"loss_box_reg_roi_{gi}"] = c, b
-            else:
-                res = self.post_processor(lg, rg.contiguous(), proposals[idx])
-                res["labels"] = sep.org_label(gi, res["labels"])
-                out.append(res)
-        if self.training:
-            return out
-        return {k: torch.cat([r[k] for r in out]) for k in ("bbox3d", "scores", "labels")}
+        ids_g = [torch.nonzero(sep_id == gi).view(-1) for gi in range(sep.group_num)]
+        out = {}
+        for gi, (lg, rg) in enumerate(zip(sep.seperate_pred_logits(logits, ids_g), sep.seperate_pred_box(reg, ids_g))):
+            idx = ids_g[gi]
+            c, b = self.loss_evaluator(lg, rg, proposals[idx], labels[idx], reg_targets[idx])
+            out[f"loss_classifier_roi_{gi}"], out[f"loss_box_reg_roi_{gi}"] = c, b
+        return out
 
-    def forward(self, roi_features, proposals, targets=None, sep_id=None):
+    def _forward_eval_segments(self, roi_features, proposals, sep_id, example_id, n_examples):
+        """Inference for rows ordered by (example, class group): ONE box-head pass over all RoIs (as the reference:
+        the head's BatchNorm3d sees every RoI of the batch), one post-processing launch set for all segments.
+        -> list over examples of the detections dict (labels are the original class ids)."""
+        sep = self.sep
+        G = sep.group_num if (sep.need_seperate and sep_id is not None) else 1
+        dev = proposals.device
+        gid = sep_id if G > 1 else torch.zeros(proposals.shape[0], dtype=torch.int64, device=dev)
+        ex = example_id if example_id is not None else torch.zeros_like(gid)
+        seg_id = ex * G + gid
+        S = n_examples * G
+        seg_sizes = torch.bincount(seg_id, minlength=S).tolist()                  # host sizes of the segments
+        batch_ids = ex.to(torch.int32).contiguous() if n_examples > 1 else None
+        x = self.feature_extractor(roi_features, proposals, batch_ids)
+        logits, reg = self.predictor(x)
+        if G > 1:
+            assert logits.shape[1] == sep.total_classes
+            grouped = sep.grouped_classes
+        else:
+            grouped = [list(range(logits.shape[1]))]
+        segs = self.post_processor.forward_segments(logits, reg, proposals, seg_id, seg_sizes,
+                                                    [s_ % G for s_ in range(S)], grouped)
+        results = []
+        for b in range(n_examples):
+            parts = []
+            for g in range(G):
+                r = segs[b * G + g]
+                if G > 1:
+                    r = dict(r, labels=sep.org_label(g, r["labels"]))
+                parts.append(r)
+            results.append({k: torch.cat([r[k] for r in parts]) for k in ("bbox3d", "scores", "labels")})
+        return results
+
+    def forward(self, roi_features, proposals, targets=None, sep_id=None, example_id=None, n_examples=1):
+        if n_examples > 1:
+            assert not self.training
+            return self._forward_eval_segments(roi_features, proposals, sep_id, example_id, n_examples)
         if sep_id is not None:
             return self._forward_grouped(roi_features, proposals, sep_id, targets)
         if self.training:                                                        # box_head.py:96-149
@@ -566,7 +710,9 @@ class SparseRCNN(nn.Module):
         if self.training:
             if targets is None:
                 raise ValueError("In training mode, targets should be passed")
-            rpn_features, roi_features = self.backbone(points)
+            if self.batch_size_of(points) > 1:
+                raise NotImplementedError("training with more than one example per batch is not built")
+            rpn_features, roi_features = self.backbone(points[:2])
             out = self.rpn(rpn_features, targets)
             proposals, rpn_losses = out[0].clone(), out[-1]
             sep_id = out[2] if len(out) == 4 else None
@@ -577,8 +723,20 @@ class SparseRCNN(nn.Module):
         with torch.no_grad():
             return self._forward_eval(points, return_intermediates)
 
+    @staticmethod
+    def batch_size_of(points):
+        """examples in `points` = [coords int64 [N, 3|4], feats(, batch_size)]: the explicit third entry, else 1 + the
+        largest batch index of the coordinates (one read-back; coordinates of 3 columns are one example)."""
+        if len(points) > 2 and points[2]:
+            return int(points[2])
+        coords = points[0]
+        if coords.shape[1] < 4 or coords.shape[0] == 0:
+            return 1
+        return int(coords[:, 3].max().item()) + 1
+
     def _forward_eval(self, points, return_intermediates=False):
-        return self.stage_tail(self.backbone(points), return_intermediates)
+        n_examples = self.batch_size_of(points)
+        return self.stage_tail(self.backbone(points[:2]), return_intermediates, n_examples)
 
     # the three stages of a pipelined inference pass (serving.BuildingPipeline); stage_tail(backbone(points)) is the
     # plain pass
@@ -588,16 +746,22 @@ class SparseRCNN(nn.Module):
     def stage_features(self, net):
         return self.backbone.stage_features(net)
 
-    def stage_tail(self, features, return_intermediates=False):
+    def stage_tail(self, features, return_intermediates=False, n_examples=1):
+        """-> detections dict of the example; for n_examples > 1 (coordinates with a batch column, examples listed one
+        after the other as the reference's collate does) a list of such dicts, one per example."""
         rpn_features, roi_features = features
-        out = self.rpn(rpn_features)
+        out = self.rpn(rpn_features, n_examples=n_examples)
         proposals, objectness = out[0].clone(), out[1]
-        sep_id = out[2] if len(out) == 3 else None
+        example_id = None
+        if n_examples > 1:
+            sep_id, example_id = out[2], out[3]
+        else:
+            sep_id = out[2] if len(out) == 3 else None
         proposals[:, 3:6] = torch.clamp(proposals[:, 3:6], min=0.001)           # BoxList3D.clamp_size
-        result = self.roi_heads.box(roi_features, proposals, sep_id=sep_id)
+        result = self.roi_heads.box(roi_features, proposals, sep_id=sep_id, example_id=example_id, n_examples=n_examples)
         if return_intermediates:
             return result, {"rpn_features": rpn_features, "roi_features": roi_features,
-                            "proposals": proposals, "objectness": objectness}
+                            "proposals": proposals, "objectness": objectness, "example_id": example_id}
         return result
 
 

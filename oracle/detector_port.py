@@ -163,11 +163,14 @@ class OracleDetector:
         keep = nms_clamped(props, sk.numpy(), rc.NMS_THRESH, rc.NMS_AUG_THICKNESS_Y_Z, rc.FPN_POST_NMS_TOP_N_TEST)
         return props[keep], sk.numpy()[keep]
 
-    def pool(self, roi_maps, proposals):
+    def pool(self, roi_maps, proposals, batch_ids=None, n_examples=1):
+        """batch_ids [K]: example of every proposal (poolers_3d.py:112-118 writes it into column 0 of the RoI)."""
         head = self.cfg.MODEL.ROI_BOX_HEAD
         p = np.asarray(proposals, np.float32).copy()
         p[:, 0:6] *= self.cfg.SPARSE3D.VOXEL_SCALE
         rois = rois_from_boxes(p)
+        if batch_ids is not None:
+            rois[:, 0] = np.asarray(batch_ids, np.float32)
         size = np.sqrt(p[:, 3:5].max(1))
         dif = np.abs(np.asarray(head.POOLER_SCALES_SPATIAL, np.float32)[None] - (size / np.float32(head.CANONICAL_SIZE))[:, None])
         levels = dif.argmin(1)
@@ -178,7 +181,7 @@ class OracleDetector:
             if not len(idx):
                 continue
             crop = loc[:, :3].max(0) + 1                                  # tools_3d_2d.py:16-29
-            dense = sparse_to_dense(f, loc, [int(v) for v in crop], 1)      # same values as crop of the full map
+            dense = sparse_to_dense(f, loc, [int(v) for v in crop], n_examples)   # same values as crop of the full map
             out[idx] = roi_align_rotated_3d(dense, rois[idx], head.POOLER_SCALES_SPATIAL[lvl], ph, pw, pz,
                                             head.POOLER_SAMPLING_RATIO)
         return out
@@ -224,3 +227,25 @@ class OracleDetector:
         props[:, 3:6] = np.maximum(props[:, 3:6], 0.001)
         logits, reg = self.box_head(self.pool(roi_maps, props))
         return self.post(logits, reg, props)
+
+    def detect_batch(self, coords, feats, n_examples):
+        """Several examples per batch (coords [N,4], examples listed one after the other): ONE backbone pass (BatchNorm
+        over all rows, as the reference), RPN selection per example (rpn/inference_3d.py:92-163), one box-head pass over
+        the RoIs of all examples, post-processing per example (box_head_3d/inference.py:66-99).
+        -> (list over examples of (boxes, scores, labels), intermediates)"""
+        rpn_maps, roi_maps = self.fpn(coords, feats)
+        props, ids = [], []
+        for b in range(n_examples):
+            maps_b = [(f[loc[:, 3] == b], loc[loc[:, 3] == b]) for f, loc in rpn_maps]
+            p, _ = self.rpn(maps_b)
+            p = p.copy()
+            p[:, 3:6] = np.maximum(p[:, 3:6], 0.001)
+            props.append(p)
+            ids.append(np.full(len(p), b, np.int32))
+        allp, allid = np.concatenate(props), np.concatenate(ids)
+        logits, reg = self.box_head(self.pool(roi_maps, allp, allid, n_examples))
+        out = []
+        for b in range(n_examples):
+            m = torch.from_numpy(allid == b)
+            out.append(self.post(logits[m], reg[m], allp[allid == b]))
+        return out, {"proposals": props, "logits": logits, "reg": reg, "rpn_maps": rpn_maps, "roi_maps": roi_maps}
