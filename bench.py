@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--points", type=int, default=500_000)
     ap.add_argument("--scenes", type=int, default=4, help="distinct synthetic scenes cycled per rank")
     ap.add_argument("--in-flight", type=int, default=2, help="buildings in flight of the extra `pipelined` region (1: skip it)")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the extra `bf16_bs4` region (BASELINE.json configs[4])")
+    ap.add_argument("--bf16-points", type=int, default=1_000_000)
+    ap.add_argument("--bf16-batch", type=int, default=4)
+    ap.add_argument("--bf16-steps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-points", type=int, default=500_000)
     return ap.parse_args()
@@ -118,6 +122,63 @@ def cpu_baseline(cfg, state_dict, n_points):
             "kind": "port",
             "sample": f"{len(scenes)} synthetic buildings of {n_points} points each (the GPU workload's scene "
                       f"generator, other seeds), full detector, {dt:.1f} s wall on {threads} OpenMP threads"}
+
+
+def bf16_region(args, cfg, model, dev, rank, world, barrier):
+    """configs[4]: `--bf16-batch` examples of `--bf16-points` points per step, backbone in bf16 storage (fp32 accumulate),
+    tail in fp32; a step = voxelize each example + one batched forward pass.  Reports buildings/s and, for the bf16
+    convolution kernel with the largest summed time, its compulsory bytes per second
+    against the HBM peak -- at bf16 every sparse convolution is bandwidth-bound."""
+    from detection_3d_amd.sparseconvnet import SCN
+    from detection_3d_amd.synthetic import make_scene
+    from detection_3d_amd.voxelize import voxelize
+    B, n_pts, steps = args.bf16_batch, args.bf16_points, args.bf16_steps
+    clouds = [torch.from_numpy(make_scene(500 + rank * B + b, n_pts, (35.0, 27.0, 2.7))).to(dev) for b in range(B)]
+    prof = SCN.ConvProfiler()
+
+    def step(learn=False):
+        prof.start_scene("bf16", learn)
+        cs, fs = [], []
+        for b, pcl in enumerate(clouds):
+            c, f = voxelize(pcl, cfg.SPARSE3D.VOXEL_SCALE, cfg.SPARSE3D.VOXEL_FULL_SCALE)
+            cs.append(torch.cat([c, torch.full((c.shape[0], 1), b, dtype=torch.int64, device=dev)], 1))
+            fs.append(f)
+        return model([torch.cat(cs), torch.cat(fs), B])
+
+    model.backbone.compute_dtype = torch.bfloat16
+    try:
+        SCN.set_profiler(prof)
+        step(learn=True)
+        res = step()
+        torch.cuda.synchronize()
+        prof.records = []
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+    finally:
+        SCN.set_profiler(None)
+        model.backbone.compute_dtype = torch.float32
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    summ = prof.summary()
+    out = {"value": round(world * B * steps / dt, 3), "unit": "buildings/s", "ms_per_step": round(1e3 * dt / steps, 3),
+           "dtype": "bf16 storage, fp32 accumulate (backbone); fp32 tail", "batch_per_gpu": B, "points_per_building": n_pts,
+           "steps": steps, "detections": [int(r["bbox3d"].shape[0]) for r in res]}
+    if summ:
+        key, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
+        sec = d["ms"] * 1e-3
+        out["roofline"] = {"bound": "hbm", "achieved": round(d["bytes"] / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(d["bytes"] / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                           "kernel": f"d3d::k_conv_bf16 (Cin={key[0]}, Cout={key[1]})",
+                           "launches_per_step": d["calls"] / steps, "avg_launch_us": round(d["ms"] / d["calls"] * 1e3, 1),
+                           "tflops": round(d["flops"] / sec / 1e12, 1),
+                           "all_sparse_conv_ms_per_step": round(sum(v["ms"] for v in summ.values()) / steps, 3)}
+    return out
 
 
 def main():
@@ -222,6 +283,15 @@ def main():
         else:
             piped = {"in_flight": args.in_flight, "value": None, "error": failed[:300]}
 
+    # third region (extra field, never `value`): BASELINE.json configs[4] -- bf16 sparse conv, ~1 M-point scenes
+    # (35 x 27 x 2.7 m), bs = 4 examples per step per GPU, same detector and weights
+    bf16 = None
+    if not args.no_bf16:
+        try:
+            bf16 = bf16_region(args, cfg, model, dev, rank, world, barrier)
+        except Exception as e:                         # noqa: BLE001 - the extra region must never cost the main line
+            bf16 = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+
     if rank == 0:
         summ = prof.summary()
         # dominant sparse-conv kernel = the k_conv template instantiation (Cin, Cout) with the largest summed time;
@@ -258,6 +328,8 @@ def main():
         }
         if piped:
             out["pipelined"] = piped
+        if bf16:
+            out["bf16_bs4"] = bf16
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, model.state_dict(), args.cpu_baseline_points)
         print(json.dumps(out), flush=True)

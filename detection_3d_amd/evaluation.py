@@ -25,6 +25,7 @@ def _gpu_iou(gt, pred, aug):
 def calc_prec_rec(preds, gts, iou_thresh, eval_aug_thickness, iou_fn=_gpu_iou):
     """preds / gts: lists (one per building) of dicts with numpy 'bbox3d' [n,7] yx_zb, 'labels' [n] (+ 'scores')."""
     n_pos, score, match, predious = defaultdict(int), defaultdict(list), defaultdict(list), defaultdict(list)
+    per_building = defaultdict(list)        # label -> [best IoU of every prediction of building i] (cal_mious input)
     for gt, pred in zip(gts, preds):
         pl, ps, pb = np.asarray(pred["labels"]), np.asarray(pred["scores"]), np.asarray(pred["bbox3d"], np.float32)
         gl, gb = np.asarray(gt["labels"]), np.asarray(gt["bbox3d"], np.float32)
@@ -45,6 +46,7 @@ def calc_prec_rec(preds, gts, iou_thresh, eval_aug_thickness, iou_fn=_gpu_iou):
             gt_index = iou.argmax(axis=0)
             gt_index[iou.max(axis=0) < iou_thresh] = -1
             predious[l].extend(iou.max(0))
+            per_building[l].append(np.asarray(iou.max(0), dtype=np.float64))
             selec = np.zeros(gb_l.shape[0], dtype=bool)
             for gi in gt_index:                                              # predictions in score order
                 if gi >= 0:
@@ -65,7 +67,24 @@ def calc_prec_rec(preds, gts, iou_thresh, eval_aug_thickness, iou_fn=_gpu_iou):
         prec[l] = tp / (fp + tp)
         with np.errstate(divide="ignore", invalid="ignore"):
             rec[l] = tp / n_pos[l]
+    calc_prec_rec.last_per_building = dict(per_building)
     return prec, rec, scores, pious
+
+
+def cal_mious(predious_per_building, iou_thresh, n_cls):
+    """suncg_eval.py:968-981 (cal_mious): per class, the mean over buildings of the mean IoU of that building's
+    predictions whose best IoU exceeds `iou_thresh`.  predious_per_building: {label: [array per building]}.
+    -> list [n_cls] (index 0 and classes without predictions: nan)."""
+    mious = [np.nan] * n_cls
+    for l, per in predious_per_building.items():
+        vals = []
+        for arr in per:
+            arr = np.asarray(arr, dtype=np.float64)
+            mask = arr > iou_thresh
+            vals.append(np.mean(arr[mask]) if mask.any() else np.nan)      # the reference takes the mean of an empty slice (nan)
+        if vals and 0 < l < n_cls:
+            mious[l] = float(np.mean(vals))
+    return mious
 
 
 def calc_ap(prec, rec, use_07_metric=True, scores=None, predious=None):
@@ -112,5 +131,10 @@ def eval_detection_suncg(preds, gts, cfg, use_07_metric=True, iou_fn=_gpu_iou):
     aug = {'target_Y': ay[0], 'anchor_Y': ay[1], 'target_Z': az[0], 'anchor_Z': az[1]}
     prec, rec, scores, pious = calc_prec_rec(preds, gts, cfg.TEST.IOU_THRESHOLD, aug, iou_fn)
     ap, table = calc_ap(prec, rec, use_07_metric, scores, pious)
-    return {"ap": ap, "map": float(np.nanmean(ap[1:])), "prec": prec, "rec": rec,
-            "recall_precision_score_iou": table}   # [n_cls, 11, 4]; [:, :, 3] are the reference's mIoU rows
+    # the IoU row the reference prints under AP (performance_str, suncg_eval.py:217,306: the table averaged over its 11
+    # recall steps, IoU column) -- the README's AIoU line; index 0 = mean over the classes like `ap`
+    with np.errstate(all="ignore"):
+        aiou = np.nanmean(table[:, :, 3], axis=1)
+    mious = cal_mious(calc_prec_rec.last_per_building, cfg.TEST.IOU_THRESHOLD, len(prec))
+    return {"ap": ap, "map": float(np.nanmean(ap[1:])), "prec": prec, "rec": rec, "aiou": aiou, "mious": mious,
+            "recall_precision_score_iou": table}   # [n_cls, 11, 4]

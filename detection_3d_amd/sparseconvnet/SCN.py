@@ -22,6 +22,17 @@ _POOL_LOCK = threading.RLock()   # re-entrant: __del__ may run inside a locked r
 _SCRATCH = {}       # scratch tensors per (device, stream): buildings in flight on different streams never share one
 
 
+def arena_bytes_for(n_points):
+    """Arena size for a batch of `n_points` input points: the default (D3D_ARENA_MB, enough for a 500 k-point building)
+    or, for larger batches, ~2.5 KiB per point (hash grids, 27-offset rulebooks in both layouts and sort temporaries of
+    every scale, split 2/3 : 1/3 between the geometry and the feature lane) rounded up to whole GiB so that recycled
+    arenas are found again."""
+    need = int(n_points) * 2560
+    if need <= _ARENA_BYTES:
+        return _ARENA_BYTES
+    return ((need + (1 << 30) - 1) >> 30) << 30
+
+
 def _scratch_key(device):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     return (idx, _lib.raw_stream(idx))

@@ -182,6 +182,26 @@ class FPN_Net(torch.nn.Module):
             md.set_geometry_stream(None)
         return out
 
+    def unused_modules(self):
+        """Sub-modules whose parameters never receive a gradient under `skip_unused` (the reference computes some of them
+        and discards the result, fpn_net.py:186-203; others -- layers_out, linear -- it only constructs): the top-down
+        levels below the finest consumed map, their laterals and merges, unselected z-projections.  A data-parallel
+        wrapper freezes them instead of searching the graph for them every step."""
+        n_scales = len(self.m_downs)
+        needed = max(self.fpn_scales_from_top + self.roi_scales_from_top) if self.skip_unused else n_scales - 1
+        used_levels = min(n_scales - 1, needed)
+        out = [self.layers_out, self.linear]
+        out += [self.m_ups[k] for k in range(used_levels, len(self.m_ups))]
+        consumed = set(self.fpn_scales_from_top) | set(self.roi_scales_from_top)
+        # ups[k + 1] = m_mergeds[k](...) feeds heads only; the top-down path itself continues from the un-merged sum
+        out += [self.m_mergeds[k] for k in range(len(self.m_mergeds))
+                if k >= used_levels or (self.skip_unused and (k + 1) not in consumed)]
+        out += [self.m_shortcuts[j] for j in range(0, n_scales - 1 - used_levels)]
+        n3d = len(self.fpn_scales_from_top)
+        sel2d = {i - n3d for i in self.rpn_3d_2d_selector if i >= n3d} if self.skip_unused else set(range(n3d))
+        out += [self.convs_pro2d[i] for i in range(len(self.convs_pro2d)) if i not in sel2d]
+        return out
+
     def _run_down(self, m, net):
         if not (self.fuse_adds and self.residual_blocks):
             return m(net)
@@ -266,6 +286,7 @@ class FPN_Net(torch.nn.Module):
         net = self.m_shortcuts[-1](net)
         ups = [net]
         needed = max(self.fpn_scales_from_top + self.roi_scales_from_top) if self.skip_unused else n_scales - 1
+        consumed = set(self.fpn_scales_from_top) | set(self.roi_scales_from_top)
         for k in range(min(n_scales - 1, needed)):
             j = n_scales - 2 - k
             shortcut = self.m_shortcuts[j](downs[j])
@@ -274,7 +295,9 @@ class FPN_Net(torch.nn.Module):
                 net = up[1](up[0](net), residual=shortcut)
             else:
                 net = scn.add_feature_planes([self.m_ups[k](net), shortcut])
-            ups.append(self.m_mergeds[k](net))
+            # a merged map that neither the RPN nor the pooler consumes is not computed (the reference computes and
+            # drops it): the top-down path continues from `net`, the un-merged sum
+            ups.append(self.m_mergeds[k](net) if (not self.skip_unused or (k + 1) in consumed) else None)
         rpn_maps_3d = [ups[i] for i in self.fpn_scales_from_top]
         selected_2d = {i - len(rpn_maps_3d) for i in self.rpn_3d_2d_selector if i >= len(rpn_maps_3d)}
         rpn_maps_2d = [self.convs_pro2d[i](rpn_maps_3d[i]) if (i in selected_2d or not self.skip_unused) else None

@@ -24,10 +24,10 @@ def toLongTensor(dimension, x):
     return torch.full((dimension,), int(x), dtype=torch.int64)
 
 
-def Metadata(dim):
-    """sparseconvnet/metadata.py:15-16."""
+def Metadata(dim, n_points=0):
+    """sparseconvnet/metadata.py:15-16 (n_points sizes the HBM arena of large batches)."""
     assert dim == 3, "only Metadata_3 is built"
-    return SCN.Metadata_3()
+    return SCN.Metadata_3(SCN.arena_bytes_for(n_points))
 
 
 class SparseConvNetTensor(object):
@@ -233,7 +233,7 @@ class InputLayer(Module):
         return self
 
     def forward(self, input):
-        out = SparseConvNetTensor(metadata=Metadata(self.dimension), spatial_size=self.spatial_size)
+        out = SparseConvNetTensor(metadata=Metadata(self.dimension, input[0].shape[0]), spatial_size=self.spatial_size)
         feats = input[1].to(self.device) if self.device else input[1]
         out.features = _apply(_InputLayerFn, feats, out.metadata, self.spatial_size, input[0],
                                            0 if len(input) == 2 else input[2], self.mode)

@@ -81,3 +81,26 @@ def make_targets(seed=0, extent=(25.0, 19.0, 2.7)):
             labels.append(3)
         boxes.append(c)
     return np.asarray(boxes, np.float32), np.asarray(labels, np.int64)
+
+
+def yx_zb_to_standard(boxes):
+    """Inverse of scene_io.standard_to_yx_zb (utils3d/bbox3d_ops.py:158-176): yx_zb (xc, yc, z_bot, dy, dx, dz, yaw)
+    -> the dataset files' "standard" mode (xc, yc, zc, x_size, y_size, z_size, yaw in [0, pi))."""
+    b = np.array(boxes, dtype=np.float32).reshape(-1, 7)[:, [0, 1, 2, 4, 3, 5, 6]]
+    b[:, 2] = b[:, 2] + b[:, 5] * 0.5
+    yaw = b[:, 6] + np.float32(np.pi * 0.5)
+    b[:, 6] = yaw - np.floor(yaw / np.pi) * np.pi
+    return b
+
+
+def write_scene_file(path, seed=0, n_points=500_000, classes=('background', 'wall', 'window', 'door')):
+    """One synthetic building in the dataset's file format (scene_io.save_scene: `.npz`, or the reference's `.pth`):
+    the point cloud of make_scene and the boxes of make_targets per class name in standard mode."""
+    from .scene_io import save_scene
+    pcl = make_scene(seed, n_points)
+    boxes, labels = make_targets(seed)
+    per_class = {}
+    for l in np.unique(labels):
+        per_class[classes[int(l)]] = yx_zb_to_standard(boxes[labels == l])
+    save_scene(path, pcl, per_class)
+    return path

@@ -211,10 +211,66 @@ def make_lr_scheduler(cfg, optimizer, examples_per_epoch):
                              cfg.SOLVER.WARMUP_METHOD)
 
 
-def wrap_ddp(model, local_rank=None):
-    """tools/train_net_sparse3d.py:52-57: DDP without buffer broadcast.  The top-down levels that no RPN / RoI
-    map consumes never receive gradients, hence find_unused_parameters.  Backend "nccl" = RCCL."""
-    kw = dict(broadcast_buffers=False, find_unused_parameters=True)
+def freeze_unused(model):
+    """requires_grad = False for the parameters no loss depends on (FPN_Net.unused_modules): with them frozen every
+    remaining parameter gets a gradient in every step, so DistributedDataParallel needs no find_unused_parameters
+    graph walk.  -> number of parameters frozen."""
+    backbone = getattr(model, "backbone", None)
+    n = 0
+    if backbone is not None and hasattr(backbone, "unused_modules"):
+        for mod in backbone.unused_modules():
+            for p in mod.parameters():
+                if p.requires_grad:
+                    p.requires_grad_(False)
+                    n += p.numel()
+    return n
+
+
+def wrap_ddp(model, local_rank=None, freeze=True):
+    """tools/train_net_sparse3d.py:52-57: DistributedDataParallel without buffer broadcast (BatchNorm statistics are per
+    forward).  The top-down levels that no RPN / RoI map consumes never receive gradients: they are
+    frozen (`freeze`), otherwise DDP searches for them every step (find_unused_parameters).  Backend "nccl" = RCCL:
+    the bucketed all-reduce of ~137 MB of fp32 gradients overlaps the backward pass."""
+    frozen = freeze_unused(model) if freeze else 0
+    kw = dict(broadcast_buffers=False, find_unused_parameters=not (freeze and frozen > 0) and _has_unused(model))
     if local_rank is not None:
         kw.update(device_ids=[local_rank], output_device=local_rank)
     return torch.nn.parallel.DistributedDataParallel(model, **kw)
+
+
+def _has_unused(model):
+    backbone = getattr(model, "backbone", None)
+    if backbone is None or not hasattr(backbone, "unused_modules"):
+        return True      # unknown module: let DDP look
+    return any(p.requires_grad for mod in backbone.unused_modules() for p in mod.parameters())
+
+
+def reduce_loss_dict(loss_dict):
+    """maskrcnn_benchmark/engine/trainer_sparse3d.py:17-39: the 4-12 loss scalars summed onto rank 0 (one small
+    `reduce`), which divides by the world size; other ranks get their partial sums back, as in the reference."""
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if world < 2:
+        return loss_dict
+    with torch.no_grad():
+        names = sorted(loss_dict.keys())
+        all_losses = torch.stack([loss_dict[k].detach() for k in names], dim=0)
+        dist.reduce(all_losses, dst=0)
+        if dist.get_rank() == 0:
+            all_losses /= world
+        return {k: v for k, v in zip(names, all_losses)}
+
+
+def train_step(model, optimizer, scheduler, points, targets):
+    """One iteration of do_train (engine/trainer_sparse3d.py:84-123): forward -> sum of the losses -> backward (DDP
+    all-reduces the gradients bucket by bucket meanwhile) -> SGD step -> LR schedule.  -> (loss dict of this rank,
+    reduced loss dict for logging)."""
+    loss_dict = model(points, targets)
+    losses = sum(loss_dict.values())
+    reduced = reduce_loss_dict(loss_dict)
+    optimizer.zero_grad()
+    losses.backward()
+    optimizer.step()
+    if scheduler is not None:
+        scheduler.step()
+    return loss_dict, reduced

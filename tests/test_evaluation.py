@@ -65,3 +65,30 @@ def test_metric_with_hip_iou_matches_oracle_iou(dev):
     a = eval_detection_suncg(preds, gts, cfg)
     b = eval_detection_suncg(preds, gts, cfg, iou_fn=_oracle_iou)
     assert np.allclose(a["ap"], b["ap"], equal_nan=True) and 0.3 < a["map"] <= 1.0
+
+
+def test_aiou_rows_known_answers():
+    """AIoU as the reference reports it (suncg_eval.py:217,306: IoU column of the 11-step table, averaged) and
+    cal_mious (:968-981): exact predictions give 1, a known shift gives the analytic IoU of the shifted boxes."""
+    from detection_3d_amd.evaluation import cal_mious
+    cfg = get_cfg("4c_Fpn432")
+    preds, gts = zip(*[_scene(s) for s in range(3)])
+    r = eval_detection_suncg(preds, gts, cfg, iou_fn=_oracle_iou)
+    assert np.allclose(r["aiou"][1:], 1.0, atol=1e-5) and abs(r["aiou"][0] - 1.0) < 1e-5
+    assert np.allclose(r["mious"][1:], 1.0, atol=1e-5) and np.isnan(r["mious"][0])
+    # every prediction shifted 2 cm along z: the BEV IoU stays 1, the z IoU of a box of height h is (h - d)/(h + d)
+    shifted = []
+    for p in preds:
+        q = {k: v.copy() for k, v in p.items()}
+        q["bbox3d"][:, 2] += 0.02
+        shifted.append(q)
+    r2 = eval_detection_suncg(shifted, gts, cfg, iou_fn=_oracle_iou)
+    want = {}
+    for g in gts:
+        for l in np.unique(g["labels"]):
+            h = np.maximum(g["bbox3d"][g["labels"] == l][:, 5], cfg.TEST.EVAL_AUG_THICKNESS_Z_TAR_ANC[0])
+            want.setdefault(int(l), []).append(np.mean((h - 0.02) / (h + 0.02)))
+    for l, vals in want.items():
+        assert abs(r2["mious"][l] - np.mean(vals)) < 2e-3, (l, r2["mious"][l], np.mean(vals))
+        assert 0.9 < r2["aiou"][l] <= 1.0
+    assert cal_mious({1: [np.array([0.9, 0.2, 0.7]), np.array([0.5])]}, 0.3, 3)[1] == np.mean([0.8, 0.5])
