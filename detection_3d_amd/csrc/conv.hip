@@ -102,10 +102,14 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
   if (n_split > 1) {
     // offset-split launch (few rows): this workgroup keeps every n_split-th active offset and
     // writes a partial tile; k_conv_reduce sums the partials in a fixed order.
+    // by the offset's INDEX, not by its rank among the block's active offsets: which partial sum an offset of a row
+    // lands in then does not depend on the other rows of the block, so the result is independent of how rows are
+    // grouped into blocks (the grouping of large plans is not reproducible from run to run, grid.hip k_class_scatter)
     uint32_t keep = 0;
-    int ord = 0;
-    for (uint32_t m = mask; m; m &= m - 1, ord++)
-      if (ord % n_split == (int)blockIdx.y) keep |= m & (~m + 1);
+    for (uint32_t m = mask; m; m &= m - 1) {
+      const int kk = __builtin_ctz(m);
+      if (kk % n_split == (int)blockIdx.y) keep |= 1u << kk;
+    }
     mask = keep;
   }
   const int rowid = rows[blk * 32 + r];

@@ -105,10 +105,11 @@ __global__ __launch_bounds__(BPW *(COUT / 32) * 64) void k_conv_bf16(
 
   uint32_t mask = __builtin_amdgcn_readfirstlane(blkmask[blk]);
   if (n_split > 1) {
-    uint32_t keep = 0;
-    int ord = 0;
-    for (uint32_t mm = mask; mm; mm &= mm - 1, ord++)
-      if (ord % n_split == (int)blockIdx.y) keep |= mm & (~mm + 1);
+    uint32_t keep = 0;     // by offset index (not rank): independent of the block's other rows, see conv.hip
+    for (uint32_t mm = mask; mm; mm &= mm - 1) {
+      const int kk = __builtin_ctz(mm);
+      if (kk % n_split == (int)blockIdx.y) keep |= 1u << kk;
+    }
     mask = keep;
   }
   f32x16 acc;

@@ -112,6 +112,12 @@ int d3d_export_rules(d3d_meta *m, int kind, const int *in_size_host, const int *
                      const int *stride_host, int32_t *triples, long capacity, long *n_host,
                      void *stream);
 
+/* debug / measurement: grouping quality of a built rulebook.  *executed_host = 32 x the sum over the 32-row blocks of the
+ * number of filter offsets the block runs, *rules_host = (in, out) pairs; executed / rules = 1 when every block's rows
+ * share one offset mask.  kind as d3d_export_rules (2 = deconvolution view).  Synchronises.                          */
+int d3d_plan_stats(d3d_meta *m, int kind, const int *in_size_host, const int *filter_host, const int *stride_host,
+                   long *n_blocks_host, long *executed_host, long *rules_host, void *stream);
+
 /* Measurement hook (bench.py's roofline leg; no reference counterpart): the next sparse-convolution launch made by
  * the calling thread records the two HIP events (hipEvent_t, created with timing) on its stream immediately before
  * and after the k_conv kernel itself -- not the k_conv_reduce of an offset-split launch -- so that the live average
