@@ -66,7 +66,7 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
     const float *__restrict__ in, int cin, const float *__restrict__ wp,
     const int32_t *__restrict__ nbrT, int npos, const int32_t *__restrict__ rows,
     const uint32_t *__restrict__ blkmask, int n_blk, const float *__restrict__ residual,
-    float *__restrict__ out, int n_split, float *__restrict__ partial, BnPre pre) {
+    float *__restrict__ out, int n_split, float *__restrict__ partial, BnPre pre, uint32_t in_bytes) {
   constexpr int WPBLK = COUT / 32 / NT;
   static_assert(WPBLK == 1 || BPW == 1, "row blocks sharing a workgroup must be single-wave");
   constexpr int TPB = WPBLK * 64;  // threads working on one row block
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
     // writes a partial tile; k_conv_reduce sums the partials in a fixed order.
     // by the offset's INDEX, not by its rank among the block's active offsets: which partial sum an offset of a row
     // lands in then does not depend on the other rows of the block, so the result is independent of how rows are
-    // grouped into blocks (the grouping of large plans is not reproducible from run to run, grid.hip k_class_scatter)
+    // grouped into blocks (e.g. the same rows reached through plans of different builds)
     uint32_t keep = 0;
     for (uint32_t m = mask; m; m &= m - 1) {
       const int kk = __builtin_ctz(m);
@@ -148,6 +148,10 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
     }
   }
   const uint32_t lane_piece = (uint32_t)gc4 * 16u, lane_idx = (uint32_t)grow * 4u;
+  // The gathered tensor as a raw buffer of in_bytes: a row piece of an ABSENT neighbour is requested at an offset past
+  // the end, which the hardware range check answers with zeros -- no branch, no select, and nothing of a real row
+  // (row 0 used to stand in, and its NaN or Inf would have spread through the 0 * x of the commit) reaches the tile.
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)in_bytes, 0x00020000);
   auto load_idx = [&](int k) {
     const char *kb = (const char *)(nb + (size_t)k * npos);  // wave-uniform
 #pragma unroll
@@ -166,8 +170,9 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
       const int s = idx[it];
       mreal[it] = s >= 0 ? 1.f : 0.f;
       if constexpr (VEC) {
-        const char *base = (const char *)(in + ct * CT);  // wave-uniform; rows are CP * 4 bytes (< 4 GiB tensor)
-        stage[it] = *(const f32x4 *)(base + ((uint32_t)(s < 0 ? 0 : s) * (uint32_t)(CP * 4) + lane_piece));
+        // rows are CP * 4 bytes (< 4 GiB tensor); 0xfffffff0 + 16 exceeds any buffer size
+        const uint32_t off = s < 0 ? 0xfffffff0u : (uint32_t)s * (uint32_t)(CP * 4) + (uint32_t)(ct * CT * 4) + lane_piece;
+        stage[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)off, 0, 0));
       } else {
         const float *p = in + (size_t)(s < 0 ? 0 : s) * cin + ct * CT + gc4 * 4;
         const int c = ct * CT + gc4 * 4;
@@ -186,8 +191,15 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
     for (int it = 0; it < NIT; it++) {
       const int row = it * RPP + grow;
       f32x4 v = stage[it];
-      if (pre.mean) v = bn_act(v, bw, bb, pre.leak);
-      v = v * mreal[it];
+      if constexpr (VEC) {
+        // an absent row arrived as zeros; only the fused BatchNorm turns them into leaky(beta'), which the row's
+        // multiplier (0 or 1, one VALU instruction per 2 elements) takes out again -- finite times 0
+        if (pre.mean) v = bn_act(v, bw, bb, pre.leak) * mreal[it];
+      } else {
+        if (pre.mean) v = bn_act(v, bw, bb, pre.leak);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        v = mreal[it] != 0.f ? v : zero;     // a select: row 0 stood in for the absent neighbour
+      }
       if (row < 32) *(f32x4 *)(As + row * LDA + gc4 * 4) = v;
     }
   };
@@ -356,15 +368,16 @@ static int launch_t(d3d_meta *m, const Plan &p, const float *in, int cin, const 
     if (!partial) n_split = 1;  // no room: fall back to the unsplit launch
   }
   const dim3 grid((p.n_blk + BPW - 1) / BPW, n_split);
+  const uint32_t in_bytes = (uint32_t)((size_t)p.n_in * (size_t)cin * 4);   // < 4 GiB (launch_conv checks)
   const hipEvent_t ev_start = t_time_start, ev_stop = t_time_stop;
   t_time_start = t_time_stop = nullptr;
   if (ev_start) (void)hipEventRecord(ev_start, s);
   if (cin == CT * NCT)
     hipLaunchKernelGGL((k_conv<CT, NCT, COUT, NT, BPW, true>), grid, dim3(threads), 0, s, in, cin, wp, p.nbrT, npos,
-                       p.rows, p.blkmask, p.n_blk, residual, out, n_split, partial, pre);
+                       p.rows, p.blkmask, p.n_blk, residual, out, n_split, partial, pre, in_bytes);
   else
     hipLaunchKernelGGL((k_conv<CT, NCT, COUT, NT, BPW, false>), grid, dim3(threads), 0, s, in, cin, wp, p.nbrT, npos,
-                       p.rows, p.blkmask, p.n_blk, residual, out, n_split, partial, pre);
+                       p.rows, p.blkmask, p.n_blk, residual, out, n_split, partial, pre, in_bytes);
   if (ev_stop) (void)hipEventRecord(ev_stop, s);   // k_conv alone: the reduction of an offset-split launch follows
   if (n_split > 1) {
     const long total = (long)npos * (COUT / 4);

@@ -556,208 +556,6 @@ __global__ __launch_bounds__(kSmallThreads) void k_plan_small(const int32_t *__r
 }
 
 
-// ------------------------------------------------------------------------------------------
-// Grouping of the rows of a LARGE plan by neighbour mask without a full sort.  What the convolution needs is that the 32
-// rows of a block share their offset mask (k_conv skips offsets no row of the block has); rows of one mask class may come
-// in any order, and the value computed for a row does not depend on its position (a missing neighbour contributes exact
-// zeros).  A scene has few distinct masks -- a few hundred to ~20 000 for 50 000 .. 500 000 rows, and 94-98 % of the rows
-// sit in classes of 32 rows or more -- so instead of a ~19-launch merge sort of (popcount, mask) keys:
-//   k_class_count   every row's mask is inserted into an open-addressing table (one counter per distinct mask; the adds
-//                   of a wave are merged per mask first, half of the rows share 5 masks);
-//   k_class_order   ONE workgroup lists the classes of >= 32 rows, sorts them by (popcount, mask) descending -- heaviest
-//                   blocks first, as the full sort did -- and lays out their segments, followed by one segment per
-//                   popcount for the rows of the small classes (their blocks are mixed either way);
-//   k_class_scatter every row takes the next free position of its segment.
-// Nothing can overflow into a wrong plan: a row without a table slot, or a big class beyond the 8192 one workgroup
-// orders, lands in its popcount segment.  The order inside a segment depends on the arrival order of the atomics: plan arrays may differ from run to run, the
-// rulebook as a set and every feature value do not (tests compare rulebooks in canonical form and features to the bit).
-static constexpr uint32_t kClassEmpty = 0xffffffffu;   // never a mask: plans with K <= 27 only
-static constexpr int kClassMaxBig = 8192;              // classes one workgroup orders; further ones share the popcount segments
-static constexpr int kClassMinRows = 8;                // classes of fewer rows share the popcount segments too
-static constexpr int kClassThreads = 1024;
-
-struct ClassTab {
-  uint32_t *key;     // [cap] mask of the class (kClassEmpty: free)
-  int32_t *cnt;      // [cap] rows of the class
-  int32_t *base;     // [cap] first position of the class's segment, -1: small class (popcount segment)
-  int32_t *cursor;   // [cap] next free position inside the segment
-  int32_t *misc;     // [96] popcount segments: base (0..31), cursor (32..63), rows that found no table slot (64..95)
-  int cap;
-};
-
-__global__ __launch_bounds__(256) void k_class_init(ClassTab t) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < t.cap) {
-    t.key[i] = kClassEmpty;
-    t.cnt[i] = 0;
-    t.base[i] = -1;
-    t.cursor[i] = 0;
-  }
-  if (i < 96) t.misc[i] = 0;
-}
-
-__device__ __forceinline__ uint32_t class_hash(uint32_t m) {
-  m ^= m >> 15;
-  m *= 0x2c1b3c6du;
-  m ^= m >> 12;
-  m *= 0x297a2d39u;
-  m ^= m >> 15;
-  return m;
-}
-
-__global__ __launch_bounds__(256) void k_class_count(const uint32_t *__restrict__ mask, int n, ClassTab t,
-                                                     int32_t *__restrict__ slot_of_row) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < n;
-  const uint32_t m = live ? mask[i] : 0u;
-  int slot = -1;
-  if (live) {
-    uint32_t sl = class_hash(m) & (uint32_t)(t.cap - 1);
-    for (int probes = 0; probes < t.cap; probes++) {
-      // read first: half of the rows share five masks, and a CAS per row on those few words serialises the chip
-      uint32_t prev = __hip_atomic_load(&t.key[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (prev == kClassEmpty) prev = atomicCAS(&t.key[sl], kClassEmpty, m);
-      if (prev == kClassEmpty || prev == m) {
-        slot = (int)sl;
-        break;
-      }
-      sl = (sl + 1) & (uint32_t)(t.cap - 1);
-    }
-    if (slot < 0) atomicAdd(&t.misc[64 + (__popc(m) & 31)], 1);   // table full (more distinct masks than slots): the row
-    slot_of_row[i] = slot;                                        // goes to its popcount segment -- less grouping, same result
-  }
-  // one counter add per (wave, class) instead of per row
-  unsigned long long todo = __ballot(live && slot >= 0);
-  while (todo) {
-    const int lead = __ffsll((long long)todo) - 1;
-    const int s0 = __shfl(slot, lead, 64);
-    const unsigned long long same = __ballot(slot == s0) & todo;
-    if ((int)(threadIdx.x & 63) == lead) atomicAdd(&t.cnt[s0], __popcll(same));
-    todo &= ~same;
-  }
-}
-
-// one workgroup: big classes -> sorted -> segment bases; small classes -> popcount segments behind them
-__global__ __launch_bounds__(kClassThreads) void k_class_order(ClassTab t, int K) {
-  __shared__ unsigned long long ent[kClassMaxBig];   // (popcount << 27 | mask) << 32 | slot ... sorted descending
-  __shared__ int n_big;
-  __shared__ int small_rows[32];
-  __shared__ int wsum[kClassThreads / 64];
-  const int tid = threadIdx.x;
-  if (tid == 0) n_big = 0;
-  if (tid < 32) small_rows[tid] = t.misc[64 + tid];
-  __syncthreads();
-  for (int sl = tid; sl < t.cap; sl += kClassThreads) {
-    const int c = t.cnt[sl];
-    if (c <= 0) continue;
-    const uint32_t m = t.key[sl];
-    bool own = false;
-    if (c >= kClassMinRows) {
-      const int at = atomicAdd(&n_big, 1);
-      own = at < kClassMaxBig;     // more big classes than this workgroup orders: the rest share the popcount segments
-      if (own) ent[at] = ((unsigned long long)(((uint32_t)__popc(m) << 27) | m) << 32) | (uint32_t)sl;
-    }
-    if (!own) atomicAdd(&small_rows[__popc(m) & 31], c);
-  }
-  __syncthreads();
-  const int nb = min(n_big, kClassMaxBig);
-  int np2 = 1;
-  while (np2 < nb) np2 <<= 1;
-  for (int i = nb + tid; i < np2; i += kClassThreads) ent[i] = 0ull;   // pads sort last (descending)
-  __syncthreads();
-  for (int k2 = 2; k2 <= np2; k2 <<= 1)
-    for (int j = k2 >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < np2; i += kClassThreads) {
-        const int l = i ^ j;
-        if (l > i) {
-          const unsigned long long a = ent[i], b = ent[l];
-          const bool desc = (i & k2) == 0;
-          if (desc ? a < b : a > b) {
-            ent[i] = b;
-            ent[l] = a;
-          }
-        }
-      }
-      __syncthreads();
-    }
-  // exclusive scan of the big classes' counts in sorted order (ties in the key cannot happen: masks are distinct)
-  const int per = (nb + kClassThreads - 1) / kClassThreads;
-  const int i0 = min(nb, tid * per), i1 = min(nb, i0 + per);
-  int local = 0;
-  for (int i = i0; i < i1; i++) local += t.cnt[(uint32_t)ent[i]];
-  int inc = local;
-  const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int v = __shfl_up(inc, d, 64);
-    if (lane >= d) inc += v;
-  }
-  if (lane == 63) wsum[wave] = inc;
-  __syncthreads();
-  int run = inc - local;
-  for (int w = 0; w < wave; w++) run += wsum[w];
-  for (int i = i0; i < i1; i++) {
-    const uint32_t sl = (uint32_t)ent[i];
-    t.base[sl] = run;
-    run += t.cnt[sl];
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int total_big = 0;
-    for (int w = 0; w < kClassThreads / 64; w++) total_big += wsum[w];
-    int at = total_big;
-    for (int pc = min(K, 31); pc >= 0; pc--) {   // heavier popcounts first
-      t.misc[pc] = at;
-      at += small_rows[pc];
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void k_class_scatter(const uint32_t *__restrict__ mask, int n, ClassTab t,
-                                                       const int32_t *__restrict__ slot_of_row,
-                                                       int32_t *__restrict__ rows) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < n;
-  int seg = -1;            // segment id: slot of a big class, or cap + popcount of a small one
-  int base = 0;
-  if (live) {
-    const int sl = slot_of_row[i];
-    base = sl >= 0 ? t.base[sl] : -1;
-    seg = sl;
-    if (base < 0) {
-      const int pc = __popc(mask[i]) & 31;
-      base = t.misc[pc];
-      seg = t.cap + pc;
-    }
-  }
-  // one cursor add per (wave, segment); the rows of the wave take consecutive positions in lane order
-  unsigned long long todo = __ballot(live);
-  while (todo) {
-    const int lead = __ffsll((long long)todo) - 1;
-    const int s0 = __shfl(seg, lead, 64);
-    const unsigned long long same = __ballot(seg == s0) & todo;
-    int first = 0;
-    if ((int)(threadIdx.x & 63) == lead)
-      first = atomicAdd(s0 < t.cap ? &t.cursor[s0] : &t.misc[32 + (s0 - t.cap)], __popcll(same));
-    first = __shfl(first, lead, 64);
-    if (seg == s0 && live) {
-      const int rank = __popcll(same & ((1ull << (threadIdx.x & 63)) - 1ull));
-      rows[base + first + rank] = i;
-    }
-    todo &= ~same;
-  }
-}
-
-// D3D_PLAN_GROUP=1 selects class bucketing instead of the full (popcount, mask) sort of large plans (experimental: its
-// counting kernel still serialises on the few hot masks -- 0.3 ms per plan against 0.1 ms for the sort)
-static int plan_group_mode() {
-  static const int mode = [] {
-    const char *e = getenv("D3D_PLAN_GROUP");
-    return e ? atoi(e) : 0;
-  }();
-  return mode;
-}
-
 // `mask_in` (may be null): per-row offset masks already computed by the caller together with the
 // rule count in plan.n_rules_dev.  The rule count stays on the device until somebody asks for it.
 int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan, hipStream_t s,
@@ -793,36 +591,16 @@ int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan
     }
     hipLaunchKernelGGL(k_row_mask, grid1d(n_rows), dim3(256), 0, s, nbr, n_rows, K, mask);
   }
-  bool grouped = false;
-  if (K <= 27 && plan_group_mode() != 0) {
-    // class bucketing (4 launches): always correct -- rows that find no table slot, and big classes beyond the 8192 one
-    // workgroup orders, fall back to the popcount segments
-    ClassTab t;
-    t.cap = next_pow2(std::max<long>(1L << 16, (long)n_rows / 4));
-    t.key = A.get<uint32_t>(t.cap);
-    t.cnt = A.get<int32_t>(t.cap);
-    t.base = A.get<int32_t>(t.cap);
-    t.cursor = A.get<int32_t>(t.cap);
-    t.misc = A.get<int32_t>(96);
-    int32_t *slot_of_row = A.get<int32_t>(n_rows);
-    if (!t.key || !t.cnt || !t.base || !t.cursor || !t.misc || !slot_of_row) {
-      set_error("metadata arena exhausted while grouping a rulebook");
-      return D3D_ERR_NOMEM;
-    }
-    hipLaunchKernelGGL(k_class_init, grid1d(t.cap), dim3(256), 0, s, t);
-    hipLaunchKernelGGL(k_class_count, grid1d(n_rows), dim3(256), 0, s, mask, n_rows, t, slot_of_row);
-    hipLaunchKernelGGL(k_class_order, dim3(1), dim3(kClassThreads), 0, s, t, K);
-    hipLaunchKernelGGL(k_class_scatter, grid1d(n_rows), dim3(256), 0, s, mask, n_rows, t, slot_of_row, rows);
-    grouped = true;
-  }
-  if (!grouped) {
-    D3D_ALLOC(key, uint32_t, A, n_rows);
-    D3D_ALLOC(key_sorted, uint32_t, A, n_rows);
-    D3D_ALLOC(iota, int32_t, A, n_rows);
-    hipLaunchKernelGGL(k_sort_key, grid1d(n_rows), dim3(256), 0, s, mask, key, iota, n_rows, K);
-    int rc = sort_pairs_u32(key, key_sorted, iota, rows, n_rows, K <= 27 ? K + 5 : K, A, s, true);
-    if (rc) return rc;
-  }
+  // Exact, STABLE sort by (popcount, mask): rows of a mask class stay in site-id order, i.e. consecutive positions
+  // of a block read (centre offset) and write nearly consecutive feature rows.  Measured alternative: grouping the rows
+  // by hashing their masks into a class table (4 launches instead of ~19, same executed / useful steps within 10 %)
+  // hands out positions by atomics, loses that order, and made the 64 -> 64 convolutions 29 % slower.
+  D3D_ALLOC(key, uint32_t, A, n_rows);
+  D3D_ALLOC(key_sorted, uint32_t, A, n_rows);
+  D3D_ALLOC(iota, int32_t, A, n_rows);
+  hipLaunchKernelGGL(k_sort_key, grid1d(n_rows), dim3(256), 0, s, mask, key, iota, n_rows, K);
+  int rc = sort_pairs_u32(key, key_sorted, iota, rows, n_rows, K <= 27 ? K + 5 : K, A, s, true);
+  if (rc) return rc;
   hipLaunchKernelGGL(k_plan_finish, dim3((npos + kTP - 1) / kTP), dim3(256), (size_t)kTP * (K | 1) * sizeof(int32_t),
                      s, nbr, rows, n_rows, npos, K, nbrT, blkmask);
   D3D_LAUNCH_CHECK();

@@ -306,3 +306,33 @@ def test_one_parity_sites_fill_their_table_class_and_still_terminate(dev):
     assert np.array_equal(m.getSpatialLocations(out_size).cpu().numpy(), lo.astype(np.int64))
     got = canon_rules(m.export_rules(1, size, [2, 2, 2], [2, 2, 2]).cpu().numpy())
     assert np.array_equal(got, canon_rules(ru))
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_non_finite_row_stays_local(dev, fused):
+    """An absent neighbour contributes exact zeros that never pass through a real row's values: a NaN in feature row 0
+    (the row that used to stand in for absent neighbours) reaches only the outputs that really gather row 0 -- as in
+    the reference, which skips absent rules (SCN/CPU/Convolution.cpp rule loops)."""
+    from detection_3d_amd import sparseconvnet as scn
+    size = (64, 64, 16)
+    rng = np.random.RandomState(9)
+    _, coords, _ = small_scene(4, 6000, (1.2, 1.0, 0.3), size)
+    feats = rng.randn(coords.shape[0], 64).astype(np.float32)
+    t = _input(dev, coords, feats, size)
+    _, loc = oracle.input_sites(coords)
+    torch.manual_seed(2)
+    conv = scn.SubmanifoldConvolution(3, 64, 64, 3, False).to(dev)
+    f2 = t.features.clone()
+    f2[0] = float("nan")
+    x = scn.SparseConvNetTensor(f2, t.metadata, t.spatial_size)
+    nbr, _ = oracle.subm_nbr(loc, [3, 3, 3])
+    touched = np.unique(np.nonzero(nbr == 0)[0])
+    if fused:    # deferred BatchNorm with given statistics (a NaN row would poison batch statistics for every row)
+        mean, invstd = torch.zeros(64, device=dev), torch.ones(64, device=dev)
+        from detection_3d_amd.sparseconvnet.modules import _PendingBN
+        # leaky activation: with leakiness 0 the ReLU's max(t, 0) already turns a NaN into 0 (bn.hip)
+        x = _PendingBN(f2, (mean, invstd, torch.ones(64, device=dev), torch.full((64,), 0.25, device=dev), 0.333),
+                       t.metadata, t.spatial_size)
+    got = conv(x).features
+    bad = torch.nonzero(torch.isnan(got).any(1)).view(-1).cpu().numpy()
+    assert np.array_equal(bad, touched) and 0 < len(touched) < 60
