@@ -125,6 +125,7 @@ _SIGS = {
                                            vp, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_double), bn_p]),
     "d3d_deconv_forward_dt": (ctypes.c_int, [vp, c_int_p, c_int_p, c_int_p, c_int_p, vp, ctypes.c_int, vp, ctypes.c_int,
                                              vp, vp, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_double), bn_p]),
+    "d3d_conv_bf16_tuning": (ctypes.c_int, [ctypes.c_int, ctypes.c_long]),
     "d3d_bn_batch_invstd_dt": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, vp, vp, vp,
                                               ctypes.c_size_t, ctypes.c_int, vp]),
     "d3d_bn_apply_dt": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_float,

@@ -9,6 +9,7 @@
 // step's MFMAs, the result tile staged through LDS in fp32 so that the residual is added before the single rounding and
 // rows leave as 16-byte pieces.
 #include <algorithm>
+#include <cstdlib>
 
 #include "d3d_internal.h"
 
@@ -66,29 +67,36 @@ __device__ __forceinline__ u32x4 pack8(const float *f) {
   return __builtin_bit_cast(u32x4, b);
 }
 
-// CT = Cin tile staged per step (16..128), NCT tiles cover the padded Cin; BPW row blocks per workgroup (COUT == 32 only)
-template <int CT, int NCT, int COUT, int BPW>
+// CT = Cin tile staged per step (16..128), NCT tiles cover the padded Cin; BPW independent row blocks per workgroup
+// (COUT == 32 only); RB = consecutive 32-row blocks that walk the UNION of their offset masks together and share every
+// weight fragment: a wave fetches the fragments of a step once and applies them to RB accumulator tiles.  At bf16 the
+// kernel is bound by the bytes a CU can pull from L2, and with one row block per weight fetch two thirds of those bytes
+// are weights; RB = 2 / 4 cuts them to a half / a quarter (blocks are mask-sorted neighbours, so the union adds little).
+template <int CT, int NCT, int COUT, int BPW, int RB>
 __global__ __launch_bounds__(BPW *(COUT / 32) * 64) void k_conv_bf16(
     const bf16_t *__restrict__ in, const bf16_t *__restrict__ wp, const int32_t *__restrict__ nbrT, int npos,
     const int32_t *__restrict__ rows, const uint32_t *__restrict__ blkmask, int n_blk,
     const bf16_t *__restrict__ residual, bf16_t *__restrict__ out, int n_split, float *__restrict__ partial, BnPre pre) {
   constexpr int WPBLK = COUT / 32;
   static_assert(WPBLK == 1 || BPW == 1, "row blocks sharing a workgroup must be single-wave");
+  static_assert(RB == 1 || BPW == 1, "row blocks that share weight fragments form one workgroup");
   constexpr int TPB = WPBLK * 64;
+  constexpr int ROWS = 32 * RB;
   constexpr int CP = CT * NCT;
   constexpr int LDA = CT + 8;            // bf16 elements per LDS row: +16 B keeps the 16-byte pieces aligned
   constexpr int LPR = CT / 8;            // threads per gathered row (16 B each)
   constexpr int RPP = TPB / LPR;         // rows per gather pass
-  constexpr int NIT = (32 / RPP) > 0 ? (32 / RPP) : 1;
+  constexpr int NIT = (ROWS / RPP) > 0 ? (ROWS / RPP) : 1;
   constexpr int NQ = CT / 16;            // MFMAs (K = 16) per accumulator tile and step
   constexpr int LDO = COUT + 4;          // fp32 elements per row of the result tile
-  constexpr int SM_A = 32 * LDA * 2, SM_O = 32 * LDO * 4;
+  constexpr int SM_A = ROWS * LDA * 2, SM_O = 32 * LDO * 4;
   constexpr int SM = SM_A > SM_O ? SM_A : SM_O;
   __shared__ __attribute__((aligned(16))) char smem[BPW * SM];
 
   const int slot = threadIdx.x / TPB, tib = threadIdx.x % TPB;
-  const int blk = blockIdx.x * BPW + slot;
+  const int blk = (blockIdx.x * BPW + slot) * RB;      // first row block of this group
   if (blk >= n_blk) return;  // BPW > 1 only when waves are independent (no barrier below)
+  const int nsub = min(RB, n_blk - blk);               // row blocks of the group that exist
   bf16_t *As = (bf16_t *)(smem + slot * SM);
   float *Os = (float *)(smem + slot * SM);
   const int lane = tib & 63, wib = tib >> 6;
@@ -103,7 +111,10 @@ __global__ __launch_bounds__(BPW *(COUT / 32) * 64) void k_conv_bf16(
       __syncthreads();
   };
 
-  uint32_t mask = __builtin_amdgcn_readfirstlane(blkmask[blk]);
+  uint32_t mask = blkmask[blk];
+#pragma unroll
+  for (int j = 1; j < RB; j++) mask |= blkmask[min(blk + j, n_blk - 1)];
+  mask = __builtin_amdgcn_readfirstlane(mask);
   if (n_split > 1) {
     uint32_t keep = 0;     // by offset index (not rank): independent of the block's other rows, see conv.hip
     for (uint32_t mm = mask; mm; mm &= mm - 1) {
@@ -112,11 +123,14 @@ __global__ __launch_bounds__(BPW *(COUT / 32) * 64) void k_conv_bf16(
     }
     mask = keep;
   }
-  f32x16 acc;
+  f32x16 acc[RB];
 #pragma unroll
-  for (int i = 0; i < 16; i++) acc[i] = 0.f;
+  for (int j = 0; j < RB; j++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[j][i] = 0.f;
 
   const int32_t *nb = nbrT + (size_t)blk * 32;
+  const int rows_here = nsub * 32;
   int idx[NIT];
   u32x4 stage[NIT];
   bool absent[NIT];   // the staged piece belongs to a missing neighbour (it read row 0 and is replaced by zeros)
@@ -139,10 +153,8 @@ __global__ __launch_bounds__(BPW *(COUT / 32) * 64) void k_conv_bf16(
     const char *kb = (const char *)(nb + (size_t)k * npos);
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
-      if constexpr (RPP <= 32)
-        idx[it] = *(const int32_t *)(kb + (lane_idx + (uint32_t)(it * RPP * 4)));
-      else
-        idx[it] = grow < 32 ? *(const int32_t *)(kb + lane_idx) : -1;
+      const int row = it * RPP + grow;
+      idx[it] = row < rows_here ? *(const int32_t *)(kb + (lane_idx + (uint32_t)(it * RPP * 4))) : -1;
     }
   };
   auto issue_data = [&](int ct) {
@@ -177,7 +189,7 @@ __global__ __launch_bounds__(BPW *(COUT / 32) * 64) void k_conv_bf16(
         v = pack8(g);
       }
       if (absent[it]) v = u32x4{0u, 0u, 0u, 0u};    // exact zeros by a select: nothing of row 0 (NaN, Inf) leaks
-      if (row < 32) *(u32x4 *)(As + row * LDA + gc8 * 8) = v;
+      if (row < ROWS) *(u32x4 *)(As + row * LDA + gc8 * 8) = v;
     }
   };
   auto next_k = [&](int k) -> int {
@@ -220,8 +232,12 @@ __global__ __launch_bounds__(BPW *(COUT / 32) * 64) void k_conv_bf16(
     }
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
-      const bf16x8 a = *(const bf16x8 *)(As + r * LDA + q * 16 + h * 8);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, bcur[q]), acc, 0, 0, 0);
+      const bf16x8 b = __builtin_bit_cast(bf16x8, bcur[q]);
+#pragma unroll
+      for (int j = 0; j < RB; j++) {
+        const bf16x8 a = *(const bf16x8 *)(As + (j * 32 + r) * LDA + q * 16 + h * 8);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+      }
     }
     block_sync();
 #pragma unroll
@@ -231,39 +247,49 @@ __global__ __launch_bounds__(BPW *(COUT / 32) * 64) void k_conv_bf16(
   }
   // ---- epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) ----
   if (n_split > 1) {
-    float *pt = partial + ((size_t)blockIdx.y * npos + (size_t)blk * 32) * COUT;
 #pragma unroll
-    for (int reg = 0; reg < 16; reg++) {
-      const int row_in = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-      pt[(size_t)row_in * COUT + colbase + r] = acc[reg];
+    for (int j = 0; j < RB; j++) {
+      if (j >= nsub) break;
+      float *pt = partial + ((size_t)blockIdx.y * npos + (size_t)(blk + j) * 32) * COUT;
+#pragma unroll
+      for (int reg = 0; reg < 16; reg++) {
+        const int row_in = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        pt[(size_t)row_in * COUT + colbase + r] = acc[j][reg];
+      }
     }
     return;
   }
-  // result tile through LDS in fp32 (the A tile is dead: both syncs of the last step are behind us)
-#pragma unroll
-  for (int reg = 0; reg < 16; reg++) {
-    const int row_in = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-    Os[row_in * LDO + colbase + r] = acc[reg];
-  }
-  block_sync();
+  // result tiles through LDS in fp32, one row block at a time (the A tile is dead: both syncs of the last step are
+  // behind us), so that the residual is added before the single rounding and rows leave as 16-byte pieces
   constexpr int OPR = COUT / 8;            // threads per output row (8 channels = 16 B of bf16 each)
   constexpr int ORP = TPB / OPR;           // rows per pass (16)
   const int orow_l = tib / OPR, oc8 = tib % OPR;
 #pragma unroll
-  for (int p = 0; p < 32 / ORP; p++) {
-    const int row_in = p * ORP + orow_l;
-    const int orow = rows[blk * 32 + row_in];
-    if (orow < 0) continue;
-    const f32x4 lo = *(const f32x4 *)(Os + row_in * LDO + oc8 * 8), hi = *(const f32x4 *)(Os + row_in * LDO + oc8 * 8 + 4);
-    float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    const size_t o = (size_t)orow * COUT + oc8 * 8;
-    if (residual) {
-      float g[8];
-      unpack8(*(const u32x4 *)(residual + o), g);
+  for (int j = 0; j < RB; j++) {
+    if (j >= nsub) break;                  // uniform over the workgroup
+    if (j > 0) block_sync();               // the previous tile has been read
 #pragma unroll
-      for (int j = 0; j < 8; j++) f[j] += g[j];
+    for (int reg = 0; reg < 16; reg++) {
+      const int row_in = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      Os[row_in * LDO + colbase + r] = acc[j][reg];
     }
-    *(u32x4 *)(out + o) = pack8(f);
+    block_sync();
+#pragma unroll
+    for (int p = 0; p < 32 / ORP; p++) {
+      const int row_in = p * ORP + orow_l;
+      const int orow = rows[(blk + j) * 32 + row_in];
+      if (orow < 0) continue;
+      const f32x4 lo = *(const f32x4 *)(Os + row_in * LDO + oc8 * 8), hi = *(const f32x4 *)(Os + row_in * LDO + oc8 * 8 + 4);
+      float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      const size_t o = (size_t)orow * COUT + oc8 * 8;
+      if (residual) {
+        float g[8];
+        unpack8(*(const u32x4 *)(residual + o), g);
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) f[jj] += g[jj];
+      }
+      *(u32x4 *)(out + o) = pack8(f);
+    }
   }
 }
 
@@ -299,13 +325,13 @@ __global__ __launch_bounds__(256) void k_conv_reduce_bf16(const float *__restric
 
 static constexpr int kSplitTargetWavesB = 4096;
 
-template <int CT, int NCT, int COUT, int BPW>
+template <int CT, int NCT, int COUT, int BPW, int RB = 1>
 static int launch_tb(d3d_meta *m, const Plan &p, const bf16_t *in, const bf16_t *wp, const bf16_t *residual, bf16_t *out,
                      hipStream_t s, BnPre pre) {
   constexpr int WPBLK = COUT / 32;
   constexpr int threads = BPW * WPBLK * 64;
   const int npos = p.n_blk * 32;
-  const long waves = (long)p.n_blk * WPBLK;
+  const long waves = (long)((p.n_blk + RB - 1) / RB) * WPBLK;
   int n_split = 1;
   if (BPW == 1 && p.K > 1 && m && waves < kSplitTargetWavesB)
     n_split = (int)std::min<long>(p.K, (kSplitTargetWavesB + waves - 1) / waves);
@@ -316,11 +342,11 @@ static int launch_tb(d3d_meta *m, const Plan &p, const bf16_t *in, const bf16_t 
     partial = m->feat_arena.get<float>((size_t)n_split * npos * COUT);
     if (!partial) n_split = 1;
   }
-  const dim3 grid((p.n_blk + BPW - 1) / BPW, n_split);
+  const dim3 grid((p.n_blk + BPW * RB - 1) / (BPW * RB), n_split);
   hipEvent_t ev_start, ev_stop;
   conv_timing_take(&ev_start, &ev_stop);
   if (ev_start) (void)hipEventRecord(ev_start, s);
-  hipLaunchKernelGGL((k_conv_bf16<CT, NCT, COUT, BPW>), grid, dim3(threads), 0, s, in, wp, p.nbrT, npos, p.rows, p.blkmask,
+  hipLaunchKernelGGL((k_conv_bf16<CT, NCT, COUT, BPW, RB>), grid, dim3(threads), 0, s, in, wp, p.nbrT, npos, p.rows, p.blkmask,
                      p.n_blk, residual, out, n_split, partial, pre);
   if (ev_stop) (void)hipEventRecord(ev_stop, s);
   if (n_split > 1) {
@@ -333,9 +359,27 @@ static int launch_tb(d3d_meta *m, const Plan &p, const bf16_t *in, const bf16_t 
   return D3D_OK;
 }
 
+// row blocks sharing a weight fetch (d3d_conv_bf16_tuning): only for launches that still fill the chip afterwards
+static int g_bf16_rb = 2;
+static long g_bf16_rb_min_waves = 2L * kSplitTargetWavesB;   // waves the launch must still have
+
 template <int CT, int NCT>
 static int launch_cb(d3d_meta *m, const Plan &p, const bf16_t *in, const bf16_t *wp, int cout, const bf16_t *residual,
                      bf16_t *out, hipStream_t s, BnPre pre) {
+  const int rb = g_bf16_rb;
+  if (rb >= 2 && cout >= 64 && (long)p.n_blk * (cout / 32) >= g_bf16_rb_min_waves * rb) {
+    if (rb >= 4) {
+      switch (cout) {
+        case 64: return launch_tb<CT, NCT, 64, 1, 4>(m, p, in, wp, residual, out, s, pre);
+        case 128: return launch_tb<CT, NCT, 128, 1, 4>(m, p, in, wp, residual, out, s, pre);
+      }
+    }
+    switch (cout) {
+      case 64: return launch_tb<CT, NCT, 64, 1, 2>(m, p, in, wp, residual, out, s, pre);
+      case 128: return launch_tb<CT, NCT, 128, 1, 2>(m, p, in, wp, residual, out, s, pre);
+      case 256: return launch_tb<CT, NCT, 256, 1, 2>(m, p, in, wp, residual, out, s, pre);
+    }
+  }
   switch (cout) {
     case 32: return launch_tb<CT, NCT, 32, 4>(m, p, in, wp, residual, out, s, pre);
     case 64: return launch_tb<CT, NCT, 64, 1>(m, p, in, wp, residual, out, s, pre);
@@ -384,6 +428,13 @@ int launch_conv_bf16(d3d_meta *m, const Plan &p, const void *in_, int cin, const
 using namespace d3d;
 
 extern "C" {
+
+int d3d_conv_bf16_tuning(int row_blocks, long min_waves) {
+  D3D_REQUIRE(row_blocks == 1 || row_blocks == 2 || row_blocks == 4, "conv_bf16_tuning: row_blocks must be 1, 2 or 4");
+  g_bf16_rb = row_blocks;
+  g_bf16_rb_min_waves = min_waves >= 0 ? min_waves : 2L * kSplitTargetWavesB;
+  return D3D_OK;
+}
 
 size_t d3d_packed_weight_bytes(int fv, int cin, int cout, int dtype) {
   if (dtype == D3D_F32) return d3d_packed_weight_floats(fv, cin, cout) * sizeof(float);

@@ -175,6 +175,10 @@ int d3d_deconv_forward_dt(d3d_meta *m, const int *in_size_host, const int *out_s
                           const int *stride_host, const void *in, int cin, const void *packed_w, int cout,
                           const void *residual, void *out, int dtype, void *stream, double *macs_host,
                           const d3d_bn_prologue *bn_host);
+/* Tuning / test hook of the bf16 convolution (process-wide): `row_blocks` (1, 2 or 4) consecutive 32-row blocks share
+ * every weight fetch in launches that keep at least min_waves * row_blocks waves (min_waves < 0: the default).
+ * Results do not depend on it beyond the summation grouping of offset-split launches.                           */
+int d3d_conv_bf16_tuning(int row_blocks, long min_waves);
 /* d3d_bn_batch_invstd / d3d_bn_apply on a tensor of the given storage type (statistics and parameters fp32). */
 int d3d_bn_batch_invstd_dt(const void *in, int rows, int planes, float eps, float *mean, float *invstd,
                            void *scratch, size_t scratch_bytes, int dtype, void *stream);

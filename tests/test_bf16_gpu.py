@@ -39,9 +39,18 @@ def _input_bf16(dev, coords, feats, size, width):
     return t, f.float().cpu().numpy()
 
 
+@pytest.fixture(params=[1, 2, 4])
+def row_blocks(request):
+    """the three weight-sharing widths of k_conv_bf16, forced on for every launch size"""
+    from detection_3d_amd._lib import check, lib
+    check(lib().d3d_conv_bf16_tuning(request.param, 0))
+    yield request.param
+    check(lib().d3d_conv_bf16_tuning(2, -1))
+
+
 @pytest.mark.parametrize("cin,cout", [(9, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (256, 128), (128, 256),
                                       (256, 256)])
-def test_conv_ops_bf16(dev, cin, cout):
+def test_conv_ops_bf16(dev, cin, cout, row_blocks):
     from detection_3d_amd import sparseconvnet as scn
     from detection_3d_amd.sparseconvnet import SCN
     size = (64, 64, 16)
@@ -80,7 +89,7 @@ def test_conv_ops_bf16(dev, cin, cout):
 
 
 @pytest.mark.parametrize("c", [32, 128, 256])
-def test_bn_prologue_bf16_fused_equals_unfused_and_oracle(dev, c):
+def test_bn_prologue_bf16_fused_equals_unfused_and_oracle(dev, c, row_blocks):
     """BatchNorm + ReLU deferred into the bf16 gather: the same bits as the materialised bf16 tensor, and both within
     tolerance of the fp32 oracle on the bf16-rounded input; a NaN in row 0 stays in the rows that gather row 0."""
     from detection_3d_amd import sparseconvnet as scn
