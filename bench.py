@@ -133,7 +133,7 @@ def bf16_region(args, cfg, model, dev, rank, world, barrier):
     from detection_3d_amd.synthetic import make_scene
     from detection_3d_amd.voxelize import voxelize
     B, n_pts, steps = args.bf16_batch, args.bf16_points, args.bf16_steps
-    clouds = [torch.from_numpy(make_scene(500 + rank * B + b, n_pts, (35.0, 27.0, 2.7))).to(dev) for b in range(B)]
+    clouds = []
     prof = SCN.ConvProfiler()
 
     def step(learn=False):
@@ -145,26 +145,37 @@ def bf16_region(args, cfg, model, dev, rank, world, barrier):
             fs.append(f)
         return model([torch.cat(cs), torch.cat(fs), B])
 
+    # every rank reaches the same barriers / reductions whether or not its own steps succeed (a rank that left through an
+    # exception while the others wait in a collective would hang the whole job)
+    failed, res = None, []
     model.backbone.compute_dtype = torch.bfloat16
+    SCN.set_profiler(prof)
     try:
-        SCN.set_profiler(prof)
+        clouds += [torch.from_numpy(make_scene(500 + rank * B + b, n_pts, (35.0, 27.0, 2.7))).to(dev) for b in range(B)]
         step(learn=True)
         res = step()
         torch.cuda.synchronize()
-        prof.records = []
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        barrier()
-        dt = time.perf_counter() - t0
-    finally:
-        SCN.set_profiler(None)
-        model.backbone.compute_dtype = torch.float32
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    except Exception as e:                             # noqa: BLE001
+        failed = f"{type(e).__name__}: {e}"
+    prof.records = []
+    barrier()
+    t0 = time.perf_counter()
+    if failed is None:
+        try:
+            for _ in range(steps):
+                step()
+        except Exception as e:                         # noqa: BLE001
+            failed = f"{type(e).__name__}: {e}"
+    barrier()
+    dt = time.perf_counter() - t0
+    SCN.set_profiler(None)
+    model.backbone.compute_dtype = torch.float32
+    t = torch.tensor([dt, 0.0 if failed is None else 1.0], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    dt = float(t[0].item())
+    if float(t[1].item()) > 0:
+        return {"value": None, "error": (failed or "another rank failed")[:300]}
     summ = prof.summary()
     out = {"value": round(world * B * steps / dt, 3), "unit": "buildings/s", "ms_per_step": round(1e3 * dt / steps, 3),
            "dtype": "bf16 storage, fp32 accumulate (backbone); fp32 tail", "batch_per_gpu": B, "points_per_building": n_pts,

@@ -581,6 +581,17 @@ int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan
     D3D_LAUNCH_CHECK();
     return D3D_OK;
   }
+  static const int strided_sort = [] {
+    const char *e = getenv("D3D_STRIDED_SORT");
+    return e ? atoi(e) : 1;
+  }();
+  if (!strided_sort && K <= 8 && !mask_in) {   // experiment: rows of a k = s = 2 plan in site order, no grouping
+    hipLaunchKernelGGL(k_iota, grid1d(n_rows), dim3(256), 0, s, rows, n_rows);
+    hipLaunchKernelGGL(k_plan_finish, dim3((npos + kTP - 1) / kTP), dim3(256), (size_t)kTP * (K | 1) * sizeof(int32_t),
+                       s, nbr, rows, n_rows, npos, K, nbrT, blkmask);
+    D3D_LAUNCH_CHECK();
+    return D3D_OK;
+  }
   size_t mark = A.used;
   uint32_t *mask = mask_in;
   if (!mask) {

@@ -11,11 +11,11 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH_SHORT="$REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --in-flight 1"
+BENCH_SHORT="$REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --in-flight 1 --no-bf16"
 for p in $PASSES; do
   case $p in
     trace)
-      rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $REPO/bench.py --steps 20 --warmup 3 \
+      rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $REPO/bench.py --steps 20 --warmup 3 --no-bf16 \
         --no-cpu-baseline --in-flight 1 > "$OUT/trace.log" 2>&1
       cp "$(find "$OUT/trace" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"
       python3 $REPO/scripts/prof_summary.py "$OUT/trace" 27 40 > "$OUT/kernel_stats.txt"
