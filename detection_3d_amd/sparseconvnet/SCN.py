@@ -17,7 +17,8 @@ from .._lib import check, ints, lib, ptr, require_gpu, stream_of
 
 _ARENA_BYTES = int(os.environ.get("D3D_ARENA_MB", "3072")) << 20   # 2/3 geometry lane + 1/3 feature lane
 _POOL = []          # recycled native metadata handles (one HBM arena each)
-_POOL_MAX = int(os.environ.get("D3D_ARENA_POOL", "8"))   # idle arenas kept (3 GiB each by default)
+_POOL_MAX = int(os.environ.get("D3D_ARENA_POOL", "8"))   # idle arenas kept (3 GiB each by default) ...
+_POOL_MAX_BYTES = int(os.environ.get("D3D_ARENA_POOL_GB", "32")) << 30   # ... and at most this much idle HBM
 _POOL_LOCK = threading.RLock()   # re-entrant: __del__ may run inside a locked region (GC)
 _SCRATCH = {}       # scratch tensors per (device, stream): buildings in flight on different streams never share one
 
@@ -192,10 +193,13 @@ class Metadata_3(object):
         if h is None or native is None or _POOL is None or _POOL_LOCK is None:
             return
         self._h = None
+        evicted = []
         with _POOL_LOCK:
             _POOL.append((self._home, self._bytes, h))
-            old = _POOL.pop(0) if len(_POOL) > _POOL_MAX else None      # evict the oldest (its stream may be gone)
-        if old is not None:
+            # evict the oldest (its stream may be gone) while too many / too much idle memory is kept
+            while len(_POOL) > _POOL_MAX or (len(_POOL) > 1 and sum(e[1] for e in _POOL) > _POOL_MAX_BYTES):
+                evicted.append(_POOL.pop(0))
+        for old in evicted:
             native.d3d_meta_destroy(old[2])
 
     def clear(self):

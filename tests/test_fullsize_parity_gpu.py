@@ -210,3 +210,57 @@ def test_6c_training_step_at_full_size(dev):
         assert torch.equal(ta.features, tb.features)
     assert a[0][0].features.shape[1] == 128 and len(a[0]) == 6 and len(a[1]) == 2
     del scn
+
+
+def test_config5_bf16_batch_of_four_1m_point_buildings(dev):
+    """BASELINE configs[4] at its stated size: bf16 sparse conv, ~1 M-point scenes (35 x 27 x 2.7 m), 4 examples per batch.
+    Integer results against the oracle at full size (site coordinates of every map handed on: exact); bf16 maps against the
+    fp32 pass of the same batch (5e-2 of the map's magnitude, the tolerance of tests/test_bf16_gpu.py for a chain of
+    layers); deterministic to the bit; every example yields detections."""
+    from detection_3d_amd.config import get_cfg
+    from detection_3d_amd.detector import build_detection_model
+    from detection_3d_amd.synthetic import make_scene
+    from detection_3d_amd.voxelize import voxelize
+    cfg = get_cfg("4c_Fpn432")
+    torch.manual_seed(4)
+    model = build_detection_model(cfg).to(dev).eval()
+    _sharpen(model)
+    B, cs, fs, cref = 4, [], [], []
+    for b in range(B):
+        pcl = make_scene(900 + b, 1_000_000, (35.0, 27.0, 2.7))
+        with torch.no_grad():
+            c, f = voxelize(torch.from_numpy(pcl).to(dev), 50, cfg.SPARSE3D.VOXEL_FULL_SCALE)
+        cs.append(torch.cat([c, torch.full((c.shape[0], 1), b, dtype=torch.int64, device=dev)], 1))
+        fs.append(f)
+        cr, _ = oracle.voxelize(pcl, 50, cfg.SPARSE3D.VOXEL_FULL_SCALE)
+        cref.append(np.concatenate([cr, np.full((cr.shape[0], 1), b, np.int64)], 1))
+    coords, feats = torch.cat(cs), torch.cat(fs)
+    assert coords.shape[0] > 3_500_000 and np.array_equal(coords.cpu().numpy(), np.concatenate(cref))
+    with torch.no_grad():
+        res32, mid32 = model([coords, feats, B], return_intermediates=True)
+        model.backbone.compute_dtype = torch.bfloat16
+        try:
+            res16, mid16 = model([coords, feats, B], return_intermediates=True)
+            res16b, mid16b = model([coords, feats, B], return_intermediates=True)
+        finally:
+            model.backbone.compute_dtype = torch.float32
+    torch.cuda.synchronize()
+    # site coordinates of the maps: exact against the oracle's rule builders at full size
+    _, loc = oracle.input_sites(np.concatenate(cref))
+    size = list(cfg.SPARSE3D.VOXEL_FULL_SCALE)
+    locs = [loc]
+    for _k in range(5):
+        size = [v // 2 for v in size]
+        lo, _ = oracle.conv_rules(locs[-1], [2, 2, 2], [2, 2, 2], size)
+        locs.append(lo)
+    roi16 = mid16["roi_features"]                       # ups[4] = scale 4 (256 x 256 x 32), ups[3] = scale 5
+    for t, want in zip(roi16, (locs[4], locs[5])):
+        assert np.array_equal(t.get_spatial_locations().cpu().numpy(), want.astype(np.int64))
+    for a, b, c in zip(mid16["rpn_features"] + roi16, mid16b["rpn_features"] + mid16b["roi_features"],
+                       mid32["rpn_features"] + mid32["roi_features"]):
+        assert torch.equal(a.features, b.features)                                   # deterministic to the bit
+        assert a.features.dtype == torch.float32 and a.features.shape == c.features.shape
+        assert rel_err(a.features.cpu().numpy(), c.features.cpu().numpy()) < 5e-2
+    assert len(res16) == B and all(r["bbox3d"].shape[0] > 0 for r in res16) and all(r["bbox3d"].shape[0] > 0 for r in res32)
+    for r, rb in zip(res16, res16b):
+        assert torch.equal(r["bbox3d"], rb["bbox3d"]) and torch.equal(r["scores"], rb["scores"])
