@@ -113,3 +113,31 @@ def test_prefetcher_to_gpu_matches_direct_upload(tmp_path, dev):
         c1, f1 = voxelize(p, 50, [4096, 4096, 512])
         c2, f2 = voxelize(torch.from_numpy(pcl).to(dev), 50, [4096, 4096, 512])
         assert torch.equal(c1, c2) and torch.equal(f1, f2)
+
+
+def test_load_scene_into_reads_the_stored_array_in_place(tmp_path):
+    """The prefetcher's read path: the float32 point cloud of an uncompressed .npz lands in the caller's buffer by one
+    readinto and equals load_scene's array; compressed / .pth scenes take the copying fallback with the same result."""
+    pcl, boxes = _scene(31, 4000)
+    f = str(tmp_path / "a.npz")
+    scene_io.save_scene(f, pcl, boxes)
+    assert scene_io._npz_stored_array(f, "pcl") is not None
+    bufs = []
+
+    def take(n):
+        bufs.append(np.full(n + 7, -1.0, np.float32))
+        return bufs[-1]
+
+    got, b2 = scene_io.load_scene_into(f, take)
+    want, b1 = scene_io.load_scene(f)
+    assert np.array_equal(got, want) and got.base is not None and np.shares_memory(got, bufs[-1])
+    assert sorted(b1) == sorted(b2) and all(np.array_equal(b1[k], b2[k]) for k in b1)
+    g = str(tmp_path / "c.npz")
+    np.savez_compressed(g, pcl=pcl, **{"box_" + k: v for k, v in boxes.items()})
+    assert scene_io._npz_stored_array(g, "pcl") is None
+    got2, _ = scene_io.load_scene_into(g, take)
+    assert np.array_equal(got2, want)
+    h = str(tmp_path / "d.pth")
+    scene_io.save_scene(h, pcl, boxes)
+    got3, _ = scene_io.load_scene_into(h, take)
+    assert np.array_equal(got3, want)
