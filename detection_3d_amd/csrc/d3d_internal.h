@@ -140,6 +140,8 @@ struct d3d_meta {
   int32_t *in_pslot = nullptr;   // hash slot of every input point (input for the point lists, built on first use)
   bool in_lists = false;         // in_off / in_idx filled (ensure_point_lists)
   d3d::Size3 in_size = {0, 0, 0};  // spatial size of the input grid
+  int32_t *iota = nullptr;         // 0 .. in_n - 1 (values of the plan sorts), written once per scene
+  int iota_n = 0;
   // pinned host words for size read-backs
   long *host_words = nullptr;
 };

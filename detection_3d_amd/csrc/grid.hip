@@ -129,15 +129,6 @@ int sort_pairs_u32(const uint32_t *keys_in, uint32_t *keys_out, const int32_t *v
   return D3D_OK;
 }
 
-// sort key of a row: (number of offsets << K) | offset mask -- rows with equal masks stay together and
-// blocks come out ordered by weight; sorted descending so that the heaviest blocks are dispatched first
-__global__ void k_sort_key(const uint32_t *__restrict__ mask, uint32_t *__restrict__ key, int32_t *iota, int n, int K) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t m = mask[i];
-  key[i] = K <= 27 ? (((uint32_t)__popc(m) << K) | m) : m;
-  iota[i] = i;
-}
 __global__ void k_iota(int32_t *p, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = i;
@@ -390,6 +381,11 @@ __global__ __launch_bounds__(1024) void k_conv_grid_small(const int32_t *__restr
 // a4. Submanifold neighbour probes (SubmanifoldConvolutionRules.h:13-45).  A 256-thread block owns 64
 // output sites; its 64*K probes are spread over the threads (independent loads in flight), the [site][k]
 // table is written coalesced, and the per-site offset masks are assembled in LDS.
+// sort key of a plan row: (number of offsets << K) | offset mask -- rows with equal masks stay together and blocks come
+// out ordered by weight (sorted descending: the heaviest blocks are dispatched first); the mask is its low K bits
+__device__ __forceinline__ uint32_t plan_key(uint32_t m, int K) { return K <= 27 ? (((uint32_t)__popc(m) << K) | m) : m; }
+__device__ __forceinline__ uint32_t plan_key_mask(uint32_t key, int K) { return K <= 27 ? (key & ((1u << K) - 1u)) : key; }
+
 static constexpr int kNbrSites = 64;
 __global__ __launch_bounds__(256) void k_subm_nbr(const int32_t *__restrict__ loc, int n, int fx, int fy,
                                                   int fz, const HashEntry *__restrict__ tab, int cap,
@@ -412,7 +408,8 @@ __global__ __launch_bounds__(256) void k_subm_nbr(const int32_t *__restrict__ lo
     if (v >= 0) atomicOr(&smask[ls], 1u << k);
   }
   __syncthreads();
-  if (threadIdx.x < ns) mask[s0 + threadIdx.x] = smask[threadIdx.x];
+  // the row's SORT KEY (popcount above the mask, plan_key): finalize_plan sorts it as it is
+  if (threadIdx.x < ns) mask[s0 + threadIdx.x] = plan_key(smask[threadIdx.x], K);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -422,7 +419,7 @@ __global__ void k_row_mask(const int32_t *__restrict__ nbr, int n, int K, uint32
   if (i >= n) return;
   uint32_t m = 0;
   for (int k = 0; k < K; k++) m |= (nbr[(size_t)i * K + k] >= 0 ? 1u : 0u) << k;
-  mask[i] = m;
+  mask[i] = plan_key(m, K);
 }
 // number of rules of a plan = valid entries of nbrT; only run when somebody asks for the MAC count
 __global__ __launch_bounds__(256) void k_count_rules(const int32_t *__restrict__ nbrT, long total,
@@ -508,7 +505,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_plan_small(const int32_t *__r
   for (int i = i0; i < i1; i++) {
     uint32_t m;
     if (mask_in)
-      m = mask_in[i];
+      m = plan_key_mask(mask_in[i], K);
     else {
       m = 0;
       for (int k = 0; k < K; k++) m |= (nbr[(size_t)i * K + k] >= 0 ? 1u : 0u) << k;
@@ -597,11 +594,9 @@ int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan
   // hands out positions by atomics, loses that order, and made the 64 -> 64 convolutions 29 % slower.  Leaving the
   // k = s = 2 plans unsorted (absent gathers cost no memory traffic) saves four sorts per building and costs the
   // strided convolutions 0.25 ms of zero tiles: 6.45 against 6.37 ms per building.
-  D3D_ALLOC(key, uint32_t, A, n_rows);
   D3D_ALLOC(key_sorted, uint32_t, A, n_rows);
-  D3D_ALLOC(iota, int32_t, A, n_rows);
-  hipLaunchKernelGGL(k_sort_key, grid1d(n_rows), dim3(256), 0, s, mask, key, iota, n_rows, K);
-  int rc = sort_pairs_u32(key, key_sorted, iota, rows, n_rows, K <= 27 ? K + 5 : K, A, s, true);
+  D3D_REQUIRE(m->iota && n_rows <= m->iota_n, "finalize_plan: %d rows exceed the input layer's %d points", n_rows, m->iota_n);
+  int rc = sort_pairs_u32(mask, key_sorted, m->iota, rows, n_rows, K <= 27 ? K + 5 : K, A, s, true);   // mask[] holds keys
   if (rc) return rc;
   hipLaunchKernelGGL(k_plan_finish, dim3((npos + kTP - 1) / kTP), dim3(256), (size_t)kTP * (K | 1) * sizeof(int32_t),
                      s, nbr, rows, n_rows, npos, K, nbrT, blkmask);
@@ -895,6 +890,8 @@ int d3d_meta_clear(d3d_meta *m) {
   m->strided_raw.clear();
   m->in_n = m->in_mode = m->in_active = 0;
   m->in_off = m->in_idx = m->in_pslot = nullptr;
+  m->iota = nullptr;
+  m->iota_n = 0;
   m->in_lists = false;
   return D3D_OK;
 }
@@ -963,6 +960,10 @@ int d3d_input_layer_build(d3d_meta *m, const int64_t *coords, int n, int ncols, 
   D3D_ALLOC(in_off, int32_t, A, (size_t)n + 2);
   D3D_ALLOC(in_idx, int32_t, A, (size_t)n + 1);
   D3D_ALLOC(pslot, int32_t, A, (size_t)n + 1);
+  D3D_ALLOC(iota, int32_t, A, (size_t)n + 1);   // 0, 1, 2, ...: the values every plan sort permutes (no grid has more rows)
+  m->iota = iota;
+  m->iota_n = n;
+  if (n > 0) hipLaunchKernelGGL(k_iota, grid1d(n), dim3(256), 0, s, iota, n);
   m->in_pslot = pslot;
   m->in_lists = false;
   m->in_size = Size3{size[0], size[1], size[2]};
