@@ -199,7 +199,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://")
+        dist.init_process_group(backend=os.environ.get("D3D_DIST_BACKEND", "nccl"), init_method="env://")   # nccl = RCCL; gloo: rehearsals of N ranks on one GPU
+    local_rank %= max(1, torch.cuda.device_count())     # (several ranks on one GPU only in gloo rehearsals)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
