@@ -315,6 +315,16 @@ def main():
             tflops = d["flops"] / d["calls"] / (per_launch_ms * 1e-3) / 1e12
             gbs = d["bytes"] / d["calls"] / (per_launch_ms * 1e-3) / 1e9
             traffic, traffic_src = pmc_traffic(kernel_name(key).split(" (")[0].replace("d3d::", ""))
+            # the same launches split by size: the family's average mixes two large launches per building that run near
+            # the kernel's ceiling with a dozen few-row ones that are bound by their launch -> index -> row -> MFMA chain
+            buckets = []
+            for lo, hi, tag in ((10e9, float("inf"), ">= 10 GFLOP"), (1e9, 10e9, "1-10 GFLOP"), (0.0, 1e9, "< 1 GFLOP")):
+                sel = [(f, s_.elapsed_time(e_)) for k_, f, _b, s_, e_ in prof.records if k_ == key and lo <= f < hi]
+                if sel:
+                    fl, ms = sum(f for f, _ in sel), sum(m for _, m in sel)
+                    buckets.append({"launches_of": tag, "launches_per_step": len(sel) / args.steps,
+                                    "share_of_time": round(ms / d["ms"], 3), "tflops": round(fl / (ms * 1e-3) / 1e12, 1),
+                                    "frac": round(fl / (ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4)})
             roof = {"bound": "mfma", "achieved": round(tflops, 3), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tflops / FP32_MATRIX_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_unit": traffic_src,
@@ -323,7 +333,7 @@ def main():
                     "algorithmic_gflop_per_launch": round(d["flops"] / d["calls"] / 1e9, 3),
                     "compulsory_GBps": round(gbs, 1), "compulsory_frac_of_hbm": round(gbs / HBM_PEAK_GBS, 4),
                     "all_sparse_conv_ms_per_step_warmup": None if conv_ms_warm is None else round(conv_ms_warm, 3),
-                    "kernels_warmup": families}
+                    "by_launch_size": buckets, "kernels_warmup": families}
         else:       # nothing was timed (no steps): the headline line is still printed
             roof = {"bound": "mfma", "achieved": None, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
                     "traffic": None, "traffic_unit": "no sparse convolution was timed"}
