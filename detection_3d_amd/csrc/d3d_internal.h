@@ -131,6 +131,9 @@ struct d3d_meta {
                           // lane_arena) -- each part is only ever used by one stream at a time
   bool geo_locked = false;        // d3d_meta_set_geometry_stream: builds are only accepted on geo_stream
   hipStream_t geo_stream = nullptr;
+  d3d::Arena plan_arena;          // third lane, carved out of feat_arena by d3d_meta_set_plan_stream: the submanifold /
+  hipStream_t plan_stream = nullptr;  // deconvolution rulebooks built on plan_stream while both other streams work
+  size_t feat_cap_full = 0;       // feat_arena.cap before the carve (restored by d3d_meta_clear)
   std::map<d3d::Size3, d3d::Grid> grids;
   std::map<d3d::PlanKey, d3d::Plan> plans;
   std::map<d3d::PlanKey, d3d::StridedRaw> strided_raw;
@@ -152,7 +155,7 @@ namespace d3d {
 int scan_exclusive_i32(const int32_t *in, int32_t *out, int n, int32_t *total_dev, Arena &scratch,
                        hipStream_t s);
 int sort_pairs_u32(const uint32_t *keys_in, uint32_t *keys_out, const int32_t *vals_in,
-                   int32_t *vals_out, int n, int end_bit, Arena &scratch, hipStream_t s, bool descending);
+                   int32_t *vals_out, int n, int bits, Arena &scratch, hipStream_t s, bool descending);
 int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan, hipStream_t s,
                   uint32_t *mask_in);
 int plan_rules(d3d_meta *m, Plan &p, hipStream_t s, long *out);

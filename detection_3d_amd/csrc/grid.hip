@@ -6,7 +6,6 @@
 #include <cstring>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 
 #include "d3d_internal.h"
 
@@ -109,23 +108,197 @@ int scan_exclusive_i32(const int32_t *in, int32_t *out, int n, int32_t *total_de
   return D3D_OK;
 }
 
-int sort_pairs_u32(const uint32_t *keys_in, uint32_t *keys_out, const int32_t *vals_in,
-                   int32_t *vals_out, int n, int end_bit, Arena &scratch, hipStream_t s, bool descending) {
-  if (n <= 0) return D3D_OK;
-  size_t tmp_bytes = 0;
-  if (descending) {
-    D3D_HIP_CHECK(rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out,
-                                                 (size_t)n, 0u, (unsigned)end_bit, s));
-    D3D_ALLOC(tmp, char, scratch, tmp_bytes);
-    D3D_HIP_CHECK(rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out,
-                                                 (size_t)n, 0u, (unsigned)end_bit, s));
-    return D3D_OK;
+// ------------------------------------------------------------------------------------------
+// Stable LSD radix sort of (uint32 key, int32 value) pairs by the low `bits` bits of the key: three launches per pass
+// and no cross-workgroup waiting -- per-tile digit histograms -> per-digit scan over the tiles -> ranked scatter -- with
+// 8-, 9- or 10-bit digits, whichever covers `bits` in the fewest passes (27 bits: 3 x 9; 19 bits: 2 x 10; 8 bits: one).
+// rocPRIM's device sort takes ~20 dependent launches of 5-7 us (block sort + merge passes) for the 10^4 .. 5*10^5 rows of
+// a rulebook -- 110-190 us, almost all launch latency -- and its Onesweep variant 25-33 us per pass at these sizes (the
+// look-back chain over a few dozen tiles is serial); this one is bound by its 3 launches per pass (~17 us).
+// Descending order sorts the complemented digits, so it is stable too.
+static constexpr int kRsThreads = 256;
+static constexpr int kRsItems = 8;
+static constexpr int kRsTile = kRsThreads * kRsItems;
+
+template <int DB>
+__device__ __forceinline__ uint32_t rs_digit(uint32_t k, int shift, bool desc) {
+  return ((desc ? ~k : k) >> shift) & ((1u << DB) - 1u);
+}
+
+// hist[digit][tile] of one pass
+template <int DB>
+__global__ __launch_bounds__(kRsThreads) void k_rs_count(const uint32_t *__restrict__ keys, int n, int n_tiles, int shift,
+                                                         int desc, uint32_t *__restrict__ hist) {
+  constexpr int BINS = 1 << DB;
+  __shared__ uint32_t h[BINS];
+  for (int b = threadIdx.x; b < BINS; b += kRsThreads) h[b] = 0;
+  __syncthreads();
+  const int base = blockIdx.x * kRsTile;
+#pragma unroll
+  for (int j = 0; j < kRsItems; j++) {
+    const int i = base + j * kRsThreads + threadIdx.x;
+    if (i < n) atomicAdd(&h[rs_digit<DB>(keys[i], shift, desc != 0)], 1u);
   }
-  D3D_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out,
-                                          (size_t)n, 0u, (unsigned)end_bit, s));
-  D3D_ALLOC(tmp, char, scratch, tmp_bytes);
-  D3D_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out,
-                                          (size_t)n, 0u, (unsigned)end_bit, s));
+  __syncthreads();
+  for (int b = threadIdx.x; b < BINS; b += kRsThreads) hist[(size_t)b * n_tiles + blockIdx.x] = h[b];
+}
+
+// one workgroup per digit: exclusive scan of its counts over the tiles (in place) and the digit's total
+__global__ __launch_bounds__(kRsThreads) void k_rs_scan(uint32_t *__restrict__ hist, int n_tiles,
+                                                        uint32_t *__restrict__ totals) {
+  __shared__ uint32_t wave_tot[kRsThreads / 64];
+  __shared__ uint32_t carry_s;
+  uint32_t *row = hist + (size_t)blockIdx.x * n_tiles;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n_tiles; base += kRsThreads) {
+    const int i = base + tid;
+    const uint32_t v = i < n_tiles ? row[i] : 0u;
+    const uint32_t incl = (uint32_t)wave_inclusive_scan((int)v, lane);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t off = carry_s;
+    for (int w = 0; w < wave; w++) off += wave_tot[w];
+    if (i < n_tiles) row[i] = off + incl - v;
+    __syncthreads();
+    if (tid == kRsThreads - 1) carry_s = off + incl;
+    __syncthreads();
+  }
+  if (tid == 0) totals[blockIdx.x] = carry_s;
+}
+
+// Ranked scatter of one tile.  Wave w owns the tile's elements [512 w, 512 w + 512) and walks them in 8 rounds of 64
+// consecutive ones; the lanes of a round that hold the same digit find each other with DB ballots, take consecutive
+// ranks behind the wave's running count of that digit, and the waves' counts are chained in wave order: the rank of an
+// element is the number of elements of its digit before it in the tile, i.e. the pass is stable.
+template <int DB>
+__global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const uint32_t *__restrict__ keys_in,
+                                                           const int32_t *__restrict__ vals_in, int n, int n_tiles,
+                                                           int shift, int desc, const uint32_t *__restrict__ hist,
+                                                           const uint32_t *__restrict__ totals,
+                                                           uint32_t *__restrict__ keys_out,
+                                                           int32_t *__restrict__ vals_out) {
+  constexpr int NW = kRsThreads / 64, BINS = 1 << DB, PER = BINS / kRsThreads;
+  __shared__ uint32_t wcnt[NW][BINS];
+  __shared__ uint32_t wave_tot[NW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int b = tid; b < NW * BINS; b += kRsThreads) (&wcnt[0][0])[b] = 0;
+  __syncthreads();
+  const int base = blockIdx.x * kRsTile + wave * (64 * kRsItems);
+  uint32_t key[kRsItems], dig[kRsItems], rank[kRsItems];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < kRsItems; r++) {
+    const int i = base + r * 64 + lane;
+    const bool ok = i < n;
+    key[r] = ok ? keys_in[i] : 0u;
+    const uint32_t d = rs_digit<DB>(key[r], shift, desc != 0);
+    dig[r] = d;
+    unsigned long long m = __ballot(ok);
+#pragma unroll
+    for (int b = 0; b < DB; b++) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long bal = __ballot(bit);
+      m &= bit ? bal : ~bal;
+    }
+    // every lane of a group reads the count before the group's first lane adds to it (LDS serves a wave in order)
+    const uint32_t before = ok ? wcnt[wave][d] : 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    rank[r] = before + (uint32_t)__popcll(m & lt);
+    if (ok && (m & lt) == 0) wcnt[wave][d] = before + (uint32_t)__popcll(m);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  __syncthreads();
+  // thread t, digits PER t .. PER t + PER - 1: where a digit of this tile starts = the digits before it (all tiles) +
+  // the same digit in the tiles before this one, then the waves in order
+  uint32_t pre[PER], sum = 0;
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    pre[j] = sum;
+    sum += totals[tid * PER + j];
+  }
+  const uint32_t incl = (uint32_t)wave_inclusive_scan((int)sum, lane);
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t first = incl - sum;
+  for (int w = 0; w < wave; w++) first += wave_tot[w];
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    const int d = tid * PER + j;
+    uint32_t off = first + pre[j] + hist[(size_t)d * n_tiles + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      const uint32_t c = wcnt[w][d];
+      wcnt[w][d] = off;
+      off += c;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kRsItems; r++) {
+    const int i = base + r * 64 + lane;
+    if (i < n) {
+      const uint32_t pos = wcnt[wave][dig[r]] + rank[r];
+      if (keys_out) keys_out[pos] = key[r];
+      vals_out[pos] = vals_in[i];
+    }
+  }
+}
+
+template <int DB>
+static void rs_pass(const uint32_t *ksrc, const int32_t *vsrc, int n, int n_tiles, int shift, bool desc, uint32_t *hist,
+                    uint32_t *totals, uint32_t *kdst, int32_t *vdst, hipStream_t s) {
+  hipLaunchKernelGGL(k_rs_count<DB>, dim3(n_tiles), dim3(kRsThreads), 0, s, ksrc, n, n_tiles, shift, desc ? 1 : 0, hist);
+  hipLaunchKernelGGL(k_rs_scan, dim3(1 << DB), dim3(kRsThreads), 0, s, hist, n_tiles, totals);
+  hipLaunchKernelGGL(k_rs_scatter<DB>, dim3(n_tiles), dim3(kRsThreads), 0, s, ksrc, vsrc, n, n_tiles, shift, desc ? 1 : 0,
+                     hist, totals, kdst, vdst);
+}
+static inline void rs_layout(int bits, int &passes, int &db) {
+  passes = std::max(1, (bits + 9) / 10);
+  db = std::min(10, std::max(8, (bits + passes - 1) / passes));
+}
+size_t sort_scratch_bytes(int n, int bits) {
+  int passes, db;
+  rs_layout(bits, passes, db);
+  const size_t tiles = ((size_t)std::max(n, 1) + kRsTile - 1) / kRsTile;
+  return (((size_t)1 << db) * (tiles + 1)) * 4 + 4 * ((size_t)std::max(n, 1) * 4 + 256) + 4096;
+}
+
+// keys_out may be null: the sorted keys are not wanted (saves the last pass's key stores).  `scratch` provides the
+// intermediate buffers and the histograms (released by the caller's mark).
+int sort_pairs_u32(const uint32_t *keys_in, uint32_t *keys_out, const int32_t *vals_in,
+                   int32_t *vals_out, int n, int bits, Arena &scratch, hipStream_t s, bool descending) {
+  if (n <= 0) return D3D_OK;
+  int passes, db;
+  rs_layout(bits, passes, db);
+  const int n_tiles = (n + kRsTile - 1) / kRsTile;
+  D3D_ALLOC(hist, uint32_t, scratch, ((size_t)n_tiles + 1) << db);
+  uint32_t *totals = hist + ((size_t)n_tiles << db);
+  uint32_t *ktmp[2] = {nullptr, nullptr};
+  int32_t *vtmp[2] = {nullptr, nullptr};
+  for (int j = 0; j < std::min(2, passes - 1); j++) {
+    D3D_ALLOC(kt, uint32_t, scratch, n);
+    D3D_ALLOC(vt, int32_t, scratch, n);
+    ktmp[j] = kt;
+    vtmp[j] = vt;
+  }
+  const uint32_t *ksrc = keys_in;
+  const int32_t *vsrc = vals_in;
+  for (int p = 0; p < passes; p++) {
+    const bool last = p == passes - 1;
+    uint32_t *kdst = last ? keys_out : ktmp[p & 1];
+    int32_t *vdst = last ? vals_out : vtmp[p & 1];
+    if (db == 8) rs_pass<8>(ksrc, vsrc, n, n_tiles, db * p, descending, hist, totals, kdst, vdst, s);
+    else if (db == 9) rs_pass<9>(ksrc, vsrc, n, n_tiles, db * p, descending, hist, totals, kdst, vdst, s);
+    else rs_pass<10>(ksrc, vsrc, n, n_tiles, db * p, descending, hist, totals, kdst, vdst, s);
+    ksrc = kdst;
+    vsrc = vdst;
+  }
+  D3D_LAUNCH_CHECK();
   return D3D_OK;
 }
 
@@ -594,9 +767,8 @@ int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan
   // hands out positions by atomics, loses that order, and made the 64 -> 64 convolutions 29 % slower.  Leaving the
   // k = s = 2 plans unsorted (absent gathers cost no memory traffic) saves four sorts per building and costs the
   // strided convolutions 0.25 ms of zero tiles: 6.45 against 6.37 ms per building.
-  D3D_ALLOC(key_sorted, uint32_t, A, n_rows);
   D3D_REQUIRE(m->iota && n_rows <= m->iota_n, "finalize_plan: %d rows exceed the input layer's %d points", n_rows, m->iota_n);
-  int rc = sort_pairs_u32(mask, key_sorted, m->iota, rows, n_rows, K <= 27 ? K + 5 : K, A, s, true);   // mask[] holds keys
+  int rc = sort_pairs_u32(mask, nullptr, m->iota, rows, n_rows, std::min(K, 32), A, s, true);   // low K bits: the mask
   if (rc) return rc;
   hipLaunchKernelGGL(k_plan_finish, dim3((npos + kTP - 1) / kTP), dim3(256), (size_t)kTP * (K | 1) * sizeof(int32_t),
                      s, nbr, rows, n_rows, npos, K, nbrT, blkmask);
@@ -609,8 +781,10 @@ int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan
 // stream builds grids + strided rulebooks in `arena`, every other stream (the feature pass: submanifold / deconvolution
 // rulebooks built by the first convolution that needs them, partial tiles, rule counts) works in `feat_arena`, so
 // neither carves temporaries out of memory the other stream may still be using.
+// A plan stream (d3d_meta_set_plan_stream) adds a third lane for the rulebooks that are views of an existing grid.
 Arena &lane_arena(d3d_meta *m, hipStream_t s) {
-  return (m->geo_locked && s != m->geo_stream) ? m->feat_arena : m->arena;
+  if (!m->geo_locked || s == m->geo_stream) return m->arena;
+  return (m->plan_stream && s == m->plan_stream) ? m->plan_arena : m->feat_arena;
 }
 
 // New grids come from the geometry stream alone.
@@ -861,7 +1035,7 @@ int d3d_meta_create(d3d_meta **out, size_t arena_bytes) {
   const size_t feat_bytes = (arena_bytes / 3) & ~size_t(255);   // second lane (see lane_arena)
   m->arena.cap = arena_bytes - feat_bytes;
   m->feat_arena.base = m->arena.base + m->arena.cap;
-  m->feat_arena.cap = feat_bytes;
+  m->feat_arena.cap = m->feat_cap_full = feat_bytes;
   e = hipHostMalloc((void **)&m->host_words, 16 * sizeof(long), hipHostMallocDefault);
   if (e != hipSuccess) {
     set_error("hipHostMalloc failed: %s", hipGetErrorString(e));
@@ -883,6 +1057,9 @@ int d3d_meta_clear(d3d_meta *m) {
   D3D_REQUIRE(m, "null metadata");
   m->arena.used = 0;
   m->feat_arena.used = 0;
+  m->feat_arena.cap = m->feat_cap_full;
+  m->plan_arena = Arena();
+  m->plan_stream = nullptr;
   m->geo_locked = false;
   m->geo_stream = nullptr;
   m->grids.clear();
@@ -899,6 +1076,26 @@ int d3d_meta_set_geometry_stream(d3d_meta *m, void *stream, int enable) {
   D3D_REQUIRE(m, "null metadata");
   m->geo_locked = enable != 0;
   m->geo_stream = enable ? (hipStream_t)stream : nullptr;
+  return D3D_OK;
+}
+int d3d_meta_set_plan_stream(d3d_meta *m, void *stream, int enable) {
+  D3D_REQUIRE(m, "null metadata");
+  if (!enable) {
+    m->plan_stream = nullptr;   // the lane's rulebooks stay where they are until d3d_meta_clear
+    return D3D_OK;
+  }
+  D3D_REQUIRE(m->geo_locked && stream && (hipStream_t)stream != m->geo_stream,
+              "d3d_meta_set_plan_stream: set a geometry stream first, and a different one");
+  if (!m->plan_arena.base) {    // first use for this scene: the upper 3/4 of the feature lane become the plan lane
+    const size_t keep = (m->feat_arena.cap / 4) & ~size_t(255);
+    D3D_REQUIRE(m->feat_arena.used <= keep, "d3d_meta_set_plan_stream: the feature lane is already %zu bytes deep",
+                m->feat_arena.used);
+    m->plan_arena.base = m->feat_arena.base + keep;
+    m->plan_arena.cap = m->feat_arena.cap - keep;
+    m->plan_arena.used = 0;
+    m->feat_arena.cap = keep;
+  }
+  m->plan_stream = (hipStream_t)stream;
   return D3D_OK;
 }
 int d3d_meta_arena_used(d3d_meta *m, size_t *bytes_host) {
@@ -1012,17 +1209,15 @@ int ensure_point_lists(d3d_meta *m, hipStream_t s) {
   Arena &A = lane_arena(m, s);
   size_t mark = A.used;
   D3D_ALLOC(psite, uint32_t, A, n);
-  D3D_ALLOC(psite_sorted, uint32_t, A, n);
-  D3D_ALLOC(iota, int32_t, A, n);
   D3D_ALLOC(cnt, int32_t, A, (size_t)n + 1);
+  D3D_REQUIRE(m->iota && n <= m->iota_n, "input layer: point index table missing");
   D3D_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int32_t) * ((size_t)n_active + 1), s));
   hipLaunchKernelGGL(k_point_site, grid1d(n), dim3(256), 0, s, m->in_pslot, it->second.tab, n, psite, cnt);
-  hipLaunchKernelGGL(k_iota, grid1d(n), dim3(256), 0, s, iota, n);
   int rc = scan_exclusive_i32(cnt, m->in_off, n_active + 1, nullptr, A, s);
   if (rc) return rc;
   int bits = 1;
   while ((1L << bits) < n_active) bits++;
-  rc = sort_pairs_u32(psite, psite_sorted, iota, m->in_idx, n, bits, A, s, false);
+  rc = sort_pairs_u32(psite, nullptr, m->iota, m->in_idx, n, bits, A, s, false);
   if (rc) return rc;
   D3D_LAUNCH_CHECK();
   A.used = mark;
@@ -1033,6 +1228,19 @@ int ensure_point_lists(d3d_meta *m, hipStream_t s) {
 
 extern "C" {
 
+
+size_t d3d_sort_scratch_bytes(int n, int bits) { return sort_scratch_bytes(n, bits); }
+int d3d_sort_pairs(const uint32_t *keys, const int32_t *vals, int n, int bits, int descending, uint32_t *keys_out,
+                   int32_t *vals_out, void *scratch, size_t scratch_bytes, void *stream) {
+  D3D_REQUIRE(n >= 0 && bits >= 1 && bits <= 32, "d3d_sort_pairs: bad arguments");
+  if (n == 0) return D3D_OK;
+  D3D_REQUIRE(keys && vals && vals_out && scratch, "d3d_sort_pairs: null pointer");
+  D3D_REQUIRE(scratch_bytes >= sort_scratch_bytes(n, bits), "d3d_sort_pairs: scratch too small");
+  Arena A;
+  A.base = (char *)scratch;
+  A.cap = scratch_bytes;
+  return sort_pairs_u32(keys, keys_out, vals, vals_out, n, bits, A, (hipStream_t)stream, descending != 0);
+}
 
 int d3d_input_layer_prepare(d3d_meta *m, void *stream) {
   D3D_REQUIRE(m, "null metadata");

@@ -24,6 +24,7 @@ from ._lib import check, lib, ptr, stream_of
 from . import sparseconvnet as scn
 from . import training as T
 from .config import class_to_label
+from .timeline import mark
 from .roi_align_rotated_3d import roi_align_rotated_3d_sparse, roi_align_rotated_3d_sparse_into, roi_prepare
 from .sparseconvnet import SCN
 
@@ -256,6 +257,7 @@ class RPNModule(nn.Module):
         objectness, box_regression = self.head([f.features for f in features_sparse])
         with torch.no_grad():
             anchors = self.anchor_generator.forward_cat(features_sparse)
+        mark("rpn head + anchors")
         assert objectness.shape[0] == box_regression.shape[0] == anchors.shape[0]
         grouped = self.sep.need_seperate and self.head.seperate_rpn > 1
         if n_examples > 1:
@@ -429,6 +431,7 @@ class FPN2MLPFeatureExtractor(nn.Module):
         (batch statistics, biased variance: F.batch_norm in training mode), fc6 reads the rows in place."""
         conv, bn = self.conv3d[0], self.conv3d[1]
         pooled = self.pooler.pool_metric(x0, p, self.voxel_scale, channels_inner=True, batch_ids=batch_ids)
+        mark("rois pooled")
         K, ph, pw, C, pz = pooled.shape
         y = torch.addmm(conv.bias, pooled.view(K * ph * pw, C * pz), conv.weight.view(conv.out_channels, C * pz).t())
         rep = y.shape[1]
@@ -436,7 +439,9 @@ class FPN2MLPFeatureExtractor(nn.Module):
         SCN.BatchNormalization_updateOutput(y, out, sm, si, y.new_zeros(rep), y.new_ones(rep), bn.weight, bn.bias,
                                             bn.eps, 0.0, True, 0.0)
         h = torch.addmm(self.fc6.bias, out.view(K, ph * pw * rep), self._fc6_rows_weight(ph * pw).t())
-        return F.relu(self.fc7(F.relu(h)))
+        h = F.relu(self.fc7(F.relu(h)))
+        mark("box features")
+        return h
 
     def forward(self, x0, proposals, batch_ids=None):
         """batch_ids: int32 [K] example of every proposal (inference with several examples per batch; the RoI op reads
@@ -750,7 +755,9 @@ class SparseRCNN(nn.Module):
         """-> detections dict of the example; for n_examples > 1 (coordinates with a batch column, examples listed one
         after the other as the reference's collate does) a list of such dicts, one per example."""
         rpn_features, roi_features = features
+        mark("backbone done")
         out = self.rpn(rpn_features, n_examples=n_examples)
+        mark("proposals")
         proposals, objectness = out[0].clone(), out[1]
         example_id = None
         if n_examples > 1:
@@ -759,6 +766,7 @@ class SparseRCNN(nn.Module):
             sep_id = out[2] if len(out) == 3 else None
         proposals[:, 3:6] = torch.clamp(proposals[:, 3:6], min=0.001)           # BoxList3D.clamp_size
         result = self.roi_heads.box(roi_features, proposals, sep_id=sep_id, example_id=example_id, n_examples=n_examples)
+        mark("detections")
         if return_intermediates:
             return result, {"rpn_features": rpn_features, "roi_features": roi_features,
                             "proposals": proposals, "objectness": objectness, "example_id": example_id}

@@ -210,6 +210,11 @@ class Metadata_3(object):
         on; None lifts the restriction."""
         check(lib().d3d_meta_set_geometry_stream(self._h, ctypes.c_void_p(raw_stream or 0), int(raw_stream is not None)))
 
+    def set_plan_stream(self, raw_stream):
+        """d3d_meta_set_plan_stream: submanifold / deconvolution rulebooks built on `raw_stream` get a lane of the arena
+        of their own (a geometry stream must be set); None ends the routing."""
+        check(lib().d3d_meta_set_plan_stream(self._h, ctypes.c_void_p(raw_stream or 0), int(raw_stream is not None)))
+
     def getNActive(self, spatial_size):
         n = ctypes.c_int(0)
         check(lib().d3d_get_n_active(self._h, ints(_size3(spatial_size)), ctypes.byref(n)))

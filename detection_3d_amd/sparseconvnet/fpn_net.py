@@ -10,13 +10,18 @@ Execution switches that do not change any returned tensor (TWO_LANE below is a t
                      computed; the reference computes and discards them (fpn_net.py:186-196).
 """
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
 from . import modules as scn
+from ..timeline import mark as _tmark
 
 TWO_LANE = True     # grid chain of the coarser levels on a side stream while the finer ones convolve
-_GEO_STREAMS = {}   # (device, caller's stream) -> high-priority side stream
+PLAN_LANE = os.environ.get("D3D_PLAN_LANE", "0") != "0"   # ... and each level's submanifold / deconvolution rulebooks on a third
+                    # (measured: 6.2-6.6 ms per building against 6.1-6.4 without -- the kernels it overlaps slow each other down)
+_GEO_STREAMS = {}   # (device, caller's stream) -> high-priority side streams
 
 
 def _is_gpu_input(net0):
@@ -24,11 +29,13 @@ def _is_gpu_input(net0):
 
 
 def _geometry_stream(main):
-    """-> (side stream, reusable per-level events) of the caller's stream"""
+    """-> (geometry stream, its reusable per-level events, plan stream, its events) of the caller's stream"""
     key = (main.device.index, main.cuda_stream)
     st = _GEO_STREAMS.get(key)
     if st is None:
         st = _GEO_STREAMS[key] = (torch.cuda.Stream(device=main.device, priority=-1),
+                                  [torch.cuda.Event() for _ in range(16)],
+                                  torch.cuda.Stream(device=main.device, priority=-1),
                                   [torch.cuda.Event() for _ in range(16)])
     return st
 
@@ -129,25 +136,36 @@ class FPN_Net(torch.nn.Module):
         return self.forward_fpn(net1)
 
     def _forward_two_lane(self, net0):
-        """Forward pass on two HIP streams: the chain of strided grids (small dependent kernels and one count
-        read-back per grid) is built on a high-priority side stream, level k+1 while the convolutions of level k --
-        and the submanifold / deconvolution rulebooks they build on first use -- run on the caller's stream, so the
-        read-backs no longer leave the GPU idle.  Same kernels on the same data as the one-stream pass
-        (bit-identical).  Meanwhile the metadata accepts new grids on the side stream only and gives each stream its
-        own part of the arena (d3d_meta_set_geometry_stream)."""
+        """Forward pass on three HIP streams: the chain of strided grids (small dependent kernels and one count
+        read-back per grid) is built on a high-priority side stream, level k+1 while the convolutions of level k run on
+        the caller's stream; the rulebooks that are views of a finished grid (3x3x3 / 1x1x1 submanifold, deconvolution)
+        are built on a third stream as soon as their grid exists, instead of by the first convolution that needs them,
+        so neither the grid chain nor the convolutions wait behind their hash probes and sorts.  Same kernels on the
+        same data as the one-stream pass (bit-identical).  Meanwhile the metadata accepts new grids on the geometry
+        stream only and gives each stream its own part of the arena (d3d_meta_set_geometry_stream / _plan_stream).
+        PLAN_LANE False: two streams, the views built on the caller's stream on first use (round 1)."""
         main = torch.cuda.current_stream(net0[1].device)
-        geo, pool = _geometry_stream(main)
+        geo, pool, plan, ppool = _geometry_stream(main)
+        if not PLAN_LANE:
+            plan = None
         plan0 = pool[-1]
+        three = (3,) * self.dimension
 
         started = []
 
         def after_input_build(md, size):
-            # the level-0 grid exists: this stream starts on its 3x3x3 rulebook (hash probes + sort, ~0.4 ms) while the
-            # side stream sorts the input layer's point lists, which the feature pass then only has to wait for
+            # the level-0 grid exists: its 3x3x3 rulebook (hash probes + sort, ~0.4 ms) starts at once while the
+            # geometry stream sorts the input layer's point lists, which the feature pass then only has to wait for
             started.append(md)
             geo.wait_stream(main)
             md.set_geometry_stream(geo.cuda_stream)
-            scn.SCN.SubmanifoldConvolution_prepare(size, (3,) * self.dimension, md)
+            if plan is not None:
+                plan.wait_stream(main)
+                md.set_plan_stream(plan.cuda_stream)
+                with torch.cuda.stream(plan):
+                    scn.SCN.SubmanifoldConvolution_prepare(size, three, md)
+            else:
+                scn.SCN.SubmanifoldConvolution_prepare(size, three, md)
             with torch.cuda.stream(geo):
                 scn.SCN.InputLayer_prepare(md)
                 plan0.record(geo)
@@ -162,16 +180,46 @@ class FPN_Net(torch.nn.Module):
         if not started:                                     # (an input layer that did not go through the hook)
             geo.wait_stream(main)
             md.set_geometry_stream(geo.cuda_stream)
-        steps, events = self._geometry_steps(net, False), []
+            if plan is not None:
+                plan.wait_stream(main)
+                md.set_plan_stream(plan.cuda_stream)
+        steps, events, pevents = self._geometry_steps(net, False, views=plan is not None), [], []
+        n_scales = len(self.m_downs)
 
         def lane(k):        # level k is about to be enqueued: build its grid now (level k-1 is already in the queue)
+            if k >= n_scales:                               # the top-down path follows: every view has to be there
+                if plan is not None:
+                    main.wait_stream(plan)
+                return
+            _tmark("host enters", k, host=True)
+            _tmark("main arrives", k, main)
             while len(events) <= k:
-                ev = pool[len(events)] if len(events) < len(pool) else torch.cuda.Event()
+                i = len(events)
+                ev = pool[i] if i < len(pool) - 1 else torch.cuda.Event()
                 with torch.cuda.stream(geo):
-                    next(steps)
+                    _tmark("geo starts", i, geo)
+                    views = next(steps)
                     ev.record(geo)
+                    _tmark("geo done", i, geo)
                 events.append(ev)
+                _tmark("host has count", i, host=True)
+                if plan is not None:
+                    pev = ppool[i] if i < len(ppool) else torch.cuda.Event()
+                    with torch.cuda.stream(plan):
+                        plan.wait_event(ev)
+                        _tmark("plan starts", i, plan)
+                        views[0]()                          # the 3x3x3 rulebook the level's blocks need
+                        pev.record(plan)
+                        _tmark("plan 3x3x3 done", i, plan)
+                        for v in views[1:]:                 # lateral and deconvolution views: needed on the way up
+                            v()
+                        _tmark("plan views done", i, plan)
+                    pevents.append(pev)
             main.wait_event(events[k])
+            if plan is not None:
+                main.wait_event(pevents[k])
+            _tmark("main continues", k, main)
+            _tmark("host leaves", k, host=True)
 
         try:
             lane(0)
@@ -179,6 +227,9 @@ class FPN_Net(torch.nn.Module):
             out = self.forward_fpn(net, prepared=True, lane=lane)
         finally:
             main.wait_stream(geo)
+            if plan is not None:
+                main.wait_stream(plan)
+                md.set_plan_stream(None)
             md.set_geometry_stream(None)
         return out
 
@@ -221,11 +272,13 @@ class FPN_Net(torch.nn.Module):
                 i += 1
         return net
 
-    def _geometry_steps(self, net, full):
+    def _geometry_steps(self, net, full, views=False):
         """Generator over the pyramid levels k = 0 .. n_scales-1: enqueues (on the current stream) everything level k
         needs -- the strided grid + rulebook k-1 -> k (one host read-back of the site count), the z-collapsing RPN
         projection grid of that level and, with `full`, the submanifold 3x3x3 / 1x1x1 rulebooks and the deconvolution
-        view k -> k-1 (otherwise built by the first convolution that needs them) -- then yields k."""
+        view k -> k-1 (otherwise built by the first convolution that needs them) -- then yields k.  With `views` it
+        yields instead the list of calls that build those rulebooks (3x3x3 first), for the caller to run on a stream of
+        its choice."""
         md, n_scales = net.metadata, len(self.m_downs)
         needed = max(self.fpn_scales_from_top + self.roi_scales_from_top) if self.skip_unused else n_scales - 1
         lowest_up = n_scales - 1 - min(n_scales - 1, needed)          # finest level the top-down path reaches
@@ -245,14 +298,16 @@ class FPN_Net(torch.nn.Module):
                 conv = pro2d[k]
                 scn.SCN.Convolution_prepare(size, (size - conv.filter_size) // conv.filter_stride + 1,
                                             conv.filter_size, conv.filter_stride, md)
+            todo = [lambda size=size: scn.SCN.SubmanifoldConvolution_prepare(size, (3,) * self.dimension, md)]
+            if k >= lowest_up:                                                                 # lateral 1x1x1
+                todo.append(lambda size=size: scn.SCN.SubmanifoldConvolution_prepare(size, (1,) * self.dimension, md))
+            if k > lowest_up:
+                todo.append(lambda size=size, k=k: scn.SCN.Deconvolution_prepare(
+                    size, sizes[k - 1], self.down_kernels[k - 1], self.down_strides[k - 1], md))
             if full:
-                scn.SCN.SubmanifoldConvolution_prepare(size, (3,) * self.dimension, md)
-                if k >= lowest_up:
-                    scn.SCN.SubmanifoldConvolution_prepare(size, (1,) * self.dimension, md)    # lateral 1x1x1
-                if k > lowest_up:
-                    scn.SCN.Deconvolution_prepare(size, sizes[k - 1], self.down_kernels[k - 1],
-                                                  self.down_strides[k - 1], md)
-            yield k
+                for f in todo:
+                    f()
+            yield todo if views else k
 
     def prepare_geometry(self, net, full=False):
         """All strided grids / rulebooks of the pyramid, built before the first feature kernel: each new grid costs
@@ -283,6 +338,9 @@ class FPN_Net(torch.nn.Module):
                 lane(k)
             net = self._run_down(m, net)
             downs.append(net)
+        if lane is not None:
+            lane(n_scales)
+        _tmark("down path done")
         net = self.m_shortcuts[-1](net)
         ups = [net]
         needed = max(self.fpn_scales_from_top + self.roi_scales_from_top) if self.skip_unused else n_scales - 1
@@ -298,6 +356,7 @@ class FPN_Net(torch.nn.Module):
             # a merged map that neither the RPN nor the pooler consumes is not computed (the reference computes and
             # drops it): the top-down path continues from `net`, the un-merged sum
             ups.append(self.m_mergeds[k](net) if (not self.skip_unused or (k + 1) in consumed) else None)
+        _tmark("top-down done")
         rpn_maps_3d = [ups[i] for i in self.fpn_scales_from_top]
         selected_2d = {i - len(rpn_maps_3d) for i in self.rpn_3d_2d_selector if i >= len(rpn_maps_3d)}
         rpn_maps_2d = [self.convs_pro2d[i](rpn_maps_3d[i]) if (i in selected_2d or not self.skip_unused) else None

@@ -54,6 +54,19 @@ int d3d_meta_arena_used(d3d_meta *m, size_t *bytes_host);
  * convolutions of the finer levels run on another one.  The caller orders the two streams with events.  Reset by
  * d3d_meta_clear.                                                                                                    */
 int d3d_meta_set_geometry_stream(d3d_meta *m, void *stream, int enable);
+/* Third lane (needs a geometry stream): rulebooks that are views of an existing grid -- submanifold, deconvolution --
+ * built on `stream` take their memory from a part of the slab of their own (the upper 3/4 of the feature lane, carved
+ * once per scene), so that they can be built while the geometry stream works on the next grid and a third stream
+ * convolves.  enable == 0 ends the routing; the rulebooks stay valid until d3d_meta_clear.                            */
+int d3d_meta_set_plan_stream(d3d_meta *m, void *stream, int enable);
+
+/* The stable radix sort behind the rulebooks' row order and the input layer's point lists (no reference counterpart: the
+ * reference keeps rulebooks in insertion order on the CPU, RuleBookIterator.h:15-32), exported so that it can be tested
+ * on its own.  Sorts (key, value) pairs by the low `bits` bits of the key, ascending or descending, stably; keys_out
+ * may be null.  `scratch`: d3d_sort_scratch_bytes(n, bits) bytes of device memory.                                     */
+size_t d3d_sort_scratch_bytes(int n, int bits);
+int d3d_sort_pairs(const uint32_t *keys, const int32_t *vals, int n, int bits, int descending, uint32_t *keys_out,
+                   int32_t *vals_out, void *scratch, size_t scratch_bytes, void *stream);
 
 /* a1. data3d/suncg_utils/suncg_dataset.py:97-177: a = xyz*scale in fp64, shift by per-axis min,
  * drop points outside [0, full_scale), trunc -> int64; feats[:,0:3] = a/scale.

@@ -1,0 +1,54 @@
+"""Where the streams of one building's pass are, level by level (FPN_Net.TIMELINE marks): for every pyramid level the
+times -- ms since the caller's stream started the pass -- at which the geometry stream starts / finishes the level's
+grid, the plan stream its rulebooks, the caller's stream arrives at the level and goes on, and the host enqueues them.
+  python scripts/lane_timeline.py [points]        D3D_PLAN_LANE=0: two streams"""
+import os, sys, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch
+from detection_3d_amd.config import get_cfg
+from detection_3d_amd.detector import build_detection_model
+from detection_3d_amd.sparseconvnet import fpn_net
+from detection_3d_amd import timeline
+from detection_3d_amd.synthetic import make_scene
+from detection_3d_amd.voxelize import voxelize
+
+n_points = int(sys.argv[1]) if len(sys.argv) > 1 else 500000
+dev = torch.device("cuda:0")
+cfg = get_cfg("4c_Fpn432")
+torch.manual_seed(0)
+model = build_detection_model(cfg).to(dev).eval()
+clouds = [torch.from_numpy(make_scene(i, n_points)).to(dev) for i in range(4)]
+with torch.no_grad():
+    for i in range(8):
+        model(list(voxelize(clouds[i % 4], 50, cfg.SPARSE3D.VOXEL_FULL_SCALE)))
+    torch.cuda.synchronize()
+    rows = {}
+    for rep in range(6):
+        inp = list(voxelize(clouds[rep % 4], 50, cfg.SPARSE3D.VOXEL_FULL_SCALE))
+        torch.cuda.synchronize()
+        timeline.MARKS = []
+        start = torch.cuda.Event(enable_timing=True)
+        start.record()
+        h0 = time.perf_counter()
+        model(inp)
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        torch.cuda.synchronize()
+        marks, timeline.MARKS = timeline.MARKS, None
+        for label, k, v in marks:
+            t = (v - h0) * 1e3 if isinstance(v, float) else start.elapsed_time(v)
+            rows.setdefault((k, label), []).append(t)
+        rows.setdefault((-1, "pass done"), []).append(start.elapsed_time(end))
+labels = ["host enters", "geo starts", "geo done", "host has count", "plan starts", "plan 3x3x3 done", "plan views done",
+          "main arrives", "main continues", "host leaves"]
+print(f"plan lane {'on' if fpn_net.PLAN_LANE else 'off'}; median of 6 passes, ms since the pass started")
+print("level " + " ".join(f"{l[:15]:>15}" for l in labels))
+for k in sorted({k for k, _ in rows if k >= 0}):
+    cells = []
+    for l in labels:
+        v = rows.get((k, l))
+        cells.append(f"{sorted(v)[len(v) // 2]:15.2f}" if v else " " * 15)
+    print(f"{k:5d} " + " ".join(cells))
+print("caller's stream after the levels:")
+for (k, l), v in sorted(((kl, v) for kl, v in rows.items() if kl[0] < 0), key=lambda t: sorted(t[1])[len(t[1]) // 2]):
+    print(f"  {l:24s} {sorted(v)[len(v) // 2]:7.2f}")
