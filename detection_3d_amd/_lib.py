@@ -17,7 +17,8 @@ vp = ctypes.c_void_p
 
 class BnPrologue(ctypes.Structure):
     """d3d_bn_prologue (include/d3d_hip.h): device pointers of the producer's BatchNorm."""
-    _fields_ = [("mean", vp), ("invstd", vp), ("weight", vp), ("bias", vp), ("leakiness", ctypes.c_float)]
+    _fields_ = [("mean", vp), ("invstd", vp), ("weight", vp), ("bias", vp), ("leakiness", ctypes.c_float),
+                ("out_stats", vp), ("out_stats_cap", ctypes.c_int), ("out_stats_rows", ctypes.POINTER(ctypes.c_int))]
 
 
 bn_p = ctypes.POINTER(BnPrologue)
@@ -129,6 +130,8 @@ _SIGS = {
     "d3d_deconv_forward_dt": (ctypes.c_int, [vp, c_int_p, c_int_p, c_int_p, c_int_p, vp, ctypes.c_int, vp, ctypes.c_int,
                                              vp, vp, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_double), bn_p]),
     "d3d_conv_bf16_tuning": (ctypes.c_int, [ctypes.c_int, ctypes.c_long]),
+    "d3d_bn_stats_from_partials": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int,
+                                                  vp, vp, vp, ctypes.c_size_t, vp]),
     "d3d_bn_batch_invstd_dt": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, vp, vp, vp,
                                               ctypes.c_size_t, ctypes.c_int, vp]),
     "d3d_bn_apply_dt": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_float,

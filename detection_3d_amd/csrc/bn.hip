@@ -2,6 +2,8 @@
 // (deterministic two-level reduction, no atomics) and one fused affine + activation pass.
 #include "d3d_internal.h"
 
+#include <type_traits>
+
 namespace d3d {
 
 static constexpr int kStatThreads = 1024;
@@ -73,16 +75,25 @@ __device__ __forceinline__ void store4(unsigned short *p, f32x4_t v) {
 //   mode 1: train -> save_mean, save_invstd (biased), running update (BatchNormalization.cpp:20-38)
 //   mode 2: mean, powf(unbiased var + eps, -0.5)   (eval with batch statistics)
 // HBM-bound: rows * C * 4 bytes read once.  The tickets are zero on entry and are left zero.
+// T = double: `x` holds src_rows rows of [2 C] column sums / sums of squares that the producing convolution left per
+// row block (d3d_bn_prologue.out_stats); slice b adds its share of them instead of reading the tensor, the rest is the
+// same two-level finish.  `rows` stays the number of tensor rows the statistics are over.
 template <typename T>
 __global__ __launch_bounds__(kStatThreads) void k_bn_stats(const T *__restrict__ x, int rows, int C,
                                                            unsigned int *tickets, double *partial, double *gpartial,
                                                            double *total, int mode, float *o0, float *o1,
                                                            float *running_mean, float *running_var, float eps,
-                                                           float momentum) {
+                                                           float momentum, int src_rows) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   __shared__ double red[4][kStatThreads];
   __shared__ int flag;
   const int tid = threadIdx.x;
+  if constexpr (std::is_same<T, double>::value) {
+    const int nb = gridDim.x, V2 = 2 * C;
+    const int per_p = (src_rows + nb - 1) / nb;
+    const int p0 = min(src_rows, (int)blockIdx.x * per_p), p1 = min(src_rows, p0 + per_p);
+    stat_reduce_rows((const double *)x + (size_t)p0 * V2, p1 - p0, V2, partial + (size_t)blockIdx.x * V2, &red[0][0]);
+  } else {
   const int C4 = C >> 2;                                    // float4 groups per row (C % 4 == 0)
   const int LPR = C4 < kStatThreads ? C4 : kStatThreads;    // threads covering one row
   const int RL = kStatThreads / LPR;                        // rows handled concurrently (LPR | 1024)
@@ -156,7 +167,9 @@ __global__ __launch_bounds__(kStatThreads) void k_bn_stats(const T *__restrict__
       }
     }
   }
+  }
   // ---- level 1: the last slice of a group to arrive adds the group's partials ----
+  const int nblk = gridDim.x, V = 2 * C;
   const int ngroups = (nblk + kStatGroup - 1) / kStatGroup;
   const int grp = blockIdx.x / kStatGroup;
   const int gsize = min(kStatGroup, nblk - grp * kStatGroup);
@@ -320,7 +333,24 @@ static int run_stats(const T *in, int rows, int C, void *scratch, size_t scratch
   double *gpartial = partial + (size_t)kStatBlocks * 2 * C;
   double *total = gpartial + (size_t)kStatMaxGroups * 2 * C;
   hipLaunchKernelGGL(k_bn_stats<T>, dim3(nblk), dim3(kStatThreads), 0, s, in, rows, C, (unsigned int *)scratch, partial,
-                     gpartial, total, mode, o0, o1, running_mean, running_var, eps, momentum);
+                     gpartial, total, mode, o0, o1, running_mean, running_var, eps, momentum, rows);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+// statistics from the column sums a convolution left per row block (src[src_rows][2 C], fp64)
+static int run_stats_partials(const double *src, int src_rows, int rows, int C, void *scratch, size_t scratch_bytes,
+                              hipStream_t s, int mode, float *mean, float *invstd, float eps) {
+  D3D_REQUIRE(C > 0 && C <= 4096 && C % 4 == 0, "batch norm: planes=%d must be a multiple of 4, <= 4096", C);
+  D3D_REQUIRE(scratch && scratch_bytes >= d3d_bn_scratch_bytes(C), "batch norm: scratch too small");
+  const int V = 2 * C, VP = V < kStatThreads ? V : kStatThreads, SL = kStatThreads / VP;
+  int nblk = (src_rows + 8 * SL - 1) / (8 * SL);   // >= 8 passes of the row lanes per workgroup
+  nblk = std::max(1, std::min(nblk, kStatBlocks));
+  double *partial = (double *)((char *)scratch + kTicketBytes);
+  double *gpartial = partial + (size_t)kStatBlocks * 2 * C;
+  double *total = gpartial + (size_t)kStatMaxGroups * 2 * C;
+  hipLaunchKernelGGL(k_bn_stats<double>, dim3(nblk), dim3(kStatThreads), 0, s, src, rows, C, (unsigned int *)scratch,
+                     partial, gpartial, total, mode, mean, invstd, nullptr, nullptr, eps, 0.f, src_rows);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }
@@ -376,6 +406,14 @@ int d3d_bn_apply(const float *in, float *out, int rows, int planes, const float 
   launch_bn_apply(in, out, rows, planes, mean, invstd, weight, bias, leakiness, s);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
+}
+
+int d3d_bn_stats_from_partials(const double *partials, int partial_rows, int rows, int planes, float eps,
+                               int want_invstd, float *mean, float *var_or_invstd, void *scratch, size_t scratch_bytes,
+                               void *stream) {
+  D3D_REQUIRE(partials && mean && var_or_invstd && partial_rows > 0 && rows > 0, "bn_stats_from_partials: bad arguments");
+  return run_stats_partials(partials, partial_rows, rows, planes, scratch, scratch_bytes, (hipStream_t)stream,
+                            want_invstd ? 2 : 0, mean, var_or_invstd, eps);
 }
 
 /* storage-type aware forms (d3d_dtype) of the two inference-side BatchNorm entry points */

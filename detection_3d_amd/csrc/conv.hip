@@ -66,7 +66,8 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
     const float *__restrict__ in, int cin, const float *__restrict__ wp,
     const int32_t *__restrict__ nbrT, int npos, const int32_t *__restrict__ rows,
     const uint32_t *__restrict__ blkmask, int n_blk, const float *__restrict__ residual,
-    float *__restrict__ out, int n_split, float *__restrict__ partial, BnPre pre, uint32_t in_bytes) {
+    float *__restrict__ out, int n_split, float *__restrict__ partial, BnPre pre, uint32_t in_bytes,
+    double *__restrict__ stat) {
   constexpr int WPBLK = COUT / 32 / NT;
   static_assert(WPBLK == 1 || BPW == 1, "row blocks sharing a workgroup must be single-wave");
   constexpr int TPB = WPBLK * 64;  // threads working on one row block
@@ -296,6 +297,11 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
   }
   // four rows at a time: residual reads first (a padded row reads row 0 and is dropped), then adds and stores --
   // no load waits for another, and the epilogue does not set the kernel's register budget
+  // `stat`: column sums and sums of squares (fp64) of the block's real rows, as they are stored -- the statistics of the
+  // BatchNorm that follows are then a fixed-order sum of n_blk small vectors instead of a second pass over the tensor
+  double cs[NT], css[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) cs[nt] = css[nt] = 0.0;
 #pragma unroll
   for (int g4 = 0; g4 < 4; g4++) {
     int orow[4];
@@ -318,25 +324,68 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
       if (orow[j] < 0) continue;
 #pragma unroll
       for (int nt = 0; nt < NT; nt++) out[(size_t)orow[j] * COUT + colbase + nt * 32 + r] = acc[nt][g4 * 4 + j];
+      if (stat) {
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+          const double d = (double)acc[nt][g4 * 4 + j];
+          cs[nt] += d;
+          css[nt] += d * d;
+        }
+      }
+    }
+  }
+  if (stat) {   // rows 0-3, 8-11, .. live in lanes 0-31, the others in lanes 32-63: both halves form the same sum
+    double *sp = stat + (size_t)blk * (2 * COUT);
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+      const double a = cs[nt] + __shfl_xor(cs[nt], 32, 64), b = css[nt] + __shfl_xor(css[nt], 32, 64);
+      if (h == 0) {
+        sp[colbase + nt * 32 + r] = a;
+        sp[COUT + colbase + nt * 32 + r] = b;
+      }
     }
   }
 }
 
-// out[rows[pos]] = sum_y partial[y][pos] (+ residual), y in increasing order
+// out[rows[pos]] = sum_y partial[y][pos] (+ residual), y in increasing order.  `stat` (may be null): per-workgroup column
+// sums / sums of squares of the rows it wrote, [gridDim.x][2 * cout] (see k_conv); a workgroup covers 1024 / cout rows.
 __global__ __launch_bounds__(256) void k_conv_reduce(const float *__restrict__ partial, int n_split,
                                                      int npos, int cout4, const int32_t *__restrict__ rows,
                                                      const float *__restrict__ residual,
-                                                     float *__restrict__ out) {
-  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long)npos * cout4) return;
-  const int pos = (int)(t / cout4), c4 = (int)(t % cout4);
-  const int orow = rows[pos];
-  if (orow < 0) return;
+                                                     float *__restrict__ out, double *__restrict__ stat) {
+  __shared__ double red[2][256][4];
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in_range = t < (long)npos * cout4;
+  const int pos = in_range ? (int)(t / cout4) : 0, c4 = (int)(t % cout4);
+  const int orow = in_range ? rows[pos] : -1;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int y = 0; y < n_split; y++) acc += *(const f32x4 *)(partial + (((size_t)y * npos + pos) * cout4 + c4) * 4);
-  const size_t o = ((size_t)orow * cout4 + c4) * 4;
-  if (residual) acc += *(const f32x4 *)(residual + o);
-  *(f32x4 *)(out + o) = acc;
+  if (orow >= 0) {
+    for (int y = 0; y < n_split; y++) acc += *(const f32x4 *)(partial + (((size_t)y * npos + pos) * cout4 + c4) * 4);
+    const size_t o = ((size_t)orow * cout4 + c4) * 4;
+    if (residual) acc += *(const f32x4 *)(residual + o);
+    *(f32x4 *)(out + o) = acc;
+  }
+  if (!stat) return;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const double d = orow >= 0 ? (double)acc[j] : 0.0;
+    red[0][threadIdx.x][j] = d;
+    red[1][threadIdx.x][j] = d * d;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < cout4) {   // (256 is a multiple of cout4: thread c4 of the first row owns channel group c4)
+    double *sp = stat + (size_t)blockIdx.x * (8 * cout4);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      double a = 0.0, b = 0.0;
+      for (int q = threadIdx.x; q < 256; q += cout4) {
+        a += red[0][q][j];
+        b += red[1][q][j];
+      }
+      sp[c4 * 4 + j] = a;
+      sp[4 * cout4 + c4 * 4 + j] = b;
+    }
+  }
 }
 
 static constexpr int kSplitTargetWaves = 4096;  // below this many waves the launch is offset-split
@@ -349,9 +398,15 @@ void conv_timing_take(hipEvent_t *start, hipEvent_t *stop) {
   t_time_start = t_time_stop = nullptr;
 }
 
+struct StatOut {   // d3d_bn_prologue.out_stats*: where the launch leaves the column statistics of its output
+  double *buf;
+  int cap;
+  int *rows_host;
+};
+
 template <int CT, int NCT, int COUT, int NT, int BPW>
 static int launch_t(d3d_meta *m, const Plan &p, const float *in, int cin, const float *wp,
-                    const float *residual, float *out, hipStream_t s, BnPre pre) {
+                    const float *residual, float *out, hipStream_t s, BnPre pre, const StatOut &so) {
   constexpr int WPBLK = COUT / 32 / NT;
   constexpr int threads = BPW * WPBLK * 64;
   const int npos = p.n_blk * 32;
@@ -368,21 +423,29 @@ static int launch_t(d3d_meta *m, const Plan &p, const float *in, int cin, const 
     if (!partial) n_split = 1;  // no room: fall back to the unsplit launch
   }
   const dim3 grid((p.n_blk + BPW - 1) / BPW, n_split);
+  // column statistics of the output for the BatchNorm that follows: one vector pair per row block, or per workgroup of
+  // the reduction when the launch is offset-split
+  const long reduce_blocks = ((long)npos * (COUT / 4) + 255) / 256;
+  const long stat_rows = n_split > 1 ? reduce_blocks : p.n_blk;
+  double *stat = (so.buf && stat_rows <= so.cap) ? so.buf : nullptr;
+  if (so.rows_host) *so.rows_host = stat ? (int)stat_rows : 0;
   const uint32_t in_bytes = (uint32_t)((size_t)p.n_in * (size_t)cin * 4);   // < 4 GiB (launch_conv checks)
   const hipEvent_t ev_start = t_time_start, ev_stop = t_time_stop;
   t_time_start = t_time_stop = nullptr;
   if (ev_start) (void)hipEventRecord(ev_start, s);
   if (cin == CT * NCT)
     hipLaunchKernelGGL((k_conv<CT, NCT, COUT, NT, BPW, true>), grid, dim3(threads), 0, s, in, cin, wp, p.nbrT, npos,
-                       p.rows, p.blkmask, p.n_blk, residual, out, n_split, partial, pre, in_bytes);
+                       p.rows, p.blkmask, p.n_blk, residual, out, n_split, partial, pre, in_bytes,
+                       n_split > 1 ? nullptr : stat);
   else
     hipLaunchKernelGGL((k_conv<CT, NCT, COUT, NT, BPW, false>), grid, dim3(threads), 0, s, in, cin, wp, p.nbrT, npos,
-                       p.rows, p.blkmask, p.n_blk, residual, out, n_split, partial, pre, in_bytes);
+                       p.rows, p.blkmask, p.n_blk, residual, out, n_split, partial, pre, in_bytes,
+                       n_split > 1 ? nullptr : stat);
   if (ev_stop) (void)hipEventRecord(ev_stop, s);   // k_conv alone: the reduction of an offset-split launch follows
   if (n_split > 1) {
     const long total = (long)npos * (COUT / 4);
     hipLaunchKernelGGL(k_conv_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, partial, n_split,
-                       npos, COUT / 4, p.rows, residual, out);
+                       npos, COUT / 4, p.rows, residual, out, stat);
     m->feat_arena.used = mark;  // stream-ordered scratch
   }
   D3D_LAUNCH_CHECK();
@@ -391,14 +454,14 @@ static int launch_t(d3d_meta *m, const Plan &p, const float *in, int cin, const 
 
 template <int CT, int NCT>
 static int launch_c(d3d_meta *m, const Plan &p, const float *in, int cin, const float *wp, int cout,
-                    const float *residual, float *out, hipStream_t s, BnPre pre) {
+                    const float *residual, float *out, hipStream_t s, BnPre pre, const StatOut &so) {
   switch (cout) {
-    case 32: return launch_t<CT, NCT, 32, 1, 4>(m, p, in, cin, wp, residual, out, s, pre);    // 4 independent waves
+    case 32: return launch_t<CT, NCT, 32, 1, 4>(m, p, in, cin, wp, residual, out, s, pre, so);    // 4 independent waves
     // (NT = 2 -- half as many waves per row block, no or fewer barriers -- measured slower; DESIGN.md lists the other
     //  variants that lost to this shape: 64-row groups, streaming workgroups, LDS-free A, shared weight tile)
-    case 64: return launch_t<CT, NCT, 64, 1, 1>(m, p, in, cin, wp, residual, out, s, pre);    // 2 waves / block
-    case 128: return launch_t<CT, NCT, 128, 1, 1>(m, p, in, cin, wp, residual, out, s, pre);  // 4 waves / block
-    case 256: return launch_t<CT, NCT, 256, 1, 1>(m, p, in, cin, wp, residual, out, s, pre);  // 8 waves / block
+    case 64: return launch_t<CT, NCT, 64, 1, 1>(m, p, in, cin, wp, residual, out, s, pre, so);    // 2 waves / block
+    case 128: return launch_t<CT, NCT, 128, 1, 1>(m, p, in, cin, wp, residual, out, s, pre, so);  // 4 waves / block
+    case 256: return launch_t<CT, NCT, 256, 1, 1>(m, p, in, cin, wp, residual, out, s, pre, so);  // 8 waves / block
   }
   set_error("convolution: Cout=%d not supported (32, 64, 128, 256)", cout);
   return D3D_ERR_UNSUPPORTED;
@@ -406,6 +469,7 @@ static int launch_c(d3d_meta *m, const Plan &p, const float *in, int cin, const 
 
 int launch_conv(d3d_meta *m, const Plan &p, const float *in, int cin, const float *packed_w, int cout,
                 const float *residual, float *out, hipStream_t s, const d3d_bn_prologue *bn) {
+  if (bn && bn->out_stats_rows) *bn->out_stats_rows = 0;
   if (p.n_rows == 0) {
     if (t_time_start) (void)hipEventRecord(t_time_start, s);
     if (t_time_stop) (void)hipEventRecord(t_time_stop, s);
@@ -416,16 +480,21 @@ int launch_conv(d3d_meta *m, const Plan &p, const float *in, int cin, const floa
   D3D_REQUIRE((size_t)p.n_in * (size_t)cin * 4 < ((size_t)1 << 32),
               "convolution: gathered tensor of %d rows x %d channels exceeds the 4 GiB of the 32-bit gather offsets", p.n_in, cin);
   BnPre pre = {nullptr, nullptr, nullptr, nullptr, 0.f};
+  StatOut so = {nullptr, 0, nullptr};
+  if (bn) {
+    so = {bn->out_stats, bn->out_stats_cap, bn->out_stats_rows};
+    if (so.rows_host) *so.rows_host = 0;
+  }
   if (bn && bn->mean) {
     D3D_REQUIRE(bn->invstd && cin % 8 == 0 && padded_cin(cin) == cin, "fused BatchNorm prologue needs Cin in {32,64,128,256}");
     pre = {bn->mean, bn->invstd, bn->weight, bn->bias, bn->leakiness};
   }
   switch (padded_cin(cin)) {
-    case 16: return launch_c<16, 1>(m, p, in, cin, packed_w, cout, residual, out, s, pre);
-    case 32: return launch_c<32, 1>(m, p, in, cin, packed_w, cout, residual, out, s, pre);
-    case 64: return launch_c<64, 1>(m, p, in, cin, packed_w, cout, residual, out, s, pre);
-    case 128: return launch_c<128, 1>(m, p, in, cin, packed_w, cout, residual, out, s, pre);
-    case 256: return launch_c<128, 2>(m, p, in, cin, packed_w, cout, residual, out, s, pre);
+    case 16: return launch_c<16, 1>(m, p, in, cin, packed_w, cout, residual, out, s, pre, so);
+    case 32: return launch_c<32, 1>(m, p, in, cin, packed_w, cout, residual, out, s, pre, so);
+    case 64: return launch_c<64, 1>(m, p, in, cin, packed_w, cout, residual, out, s, pre, so);
+    case 128: return launch_c<128, 1>(m, p, in, cin, packed_w, cout, residual, out, s, pre, so);
+    case 256: return launch_c<128, 2>(m, p, in, cin, packed_w, cout, residual, out, s, pre, so);
   }
   set_error("convolution: Cin=%d not supported (<= 256)", cin);
   return D3D_ERR_UNSUPPORTED;

@@ -392,6 +392,7 @@ static int launch_cb(d3d_meta *m, const Plan &p, const bf16_t *in, const bf16_t 
 
 int launch_conv_bf16(d3d_meta *m, const Plan &p, const void *in_, int cin, const void *packed_w, int cout,
                      const void *residual_, void *out_, hipStream_t s, const d3d_bn_prologue *bn) {
+  if (bn && bn->out_stats_rows) *bn->out_stats_rows = 0;   // column statistics are an fp32-storage feature
   const bf16_t *in = (const bf16_t *)in_, *wp = (const bf16_t *)packed_w, *residual = (const bf16_t *)residual_;
   bf16_t *out = (bf16_t *)out_;
   if (p.n_rows == 0) {

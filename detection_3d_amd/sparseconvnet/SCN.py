@@ -351,14 +351,51 @@ def InputLayer_updateOutput(m, spatial_size, input_coords, input_features, outpu
     check(lib().d3d_input_layer_forward(m._h, ptr(feats), planes, ptr(output_features), stream_of()))
 
 
-def _bn_struct(bn):
-    """bn = (mean, invstd, weight, bias, leakiness) device tensors -> d3d_bn_prologue (kept alive by caller)."""
-    if bn is None:
+def _bn_struct(bn, stats=None):
+    """bn = (mean, invstd, weight, bias, leakiness) device tensors and / or stats = (fp64 [cap, 2 Cout] tensor, c_int
+    that receives the rows written) -> d3d_bn_prologue (kept alive by caller)."""
+    if bn is None and stats is None:
         return None
-    mean, invstd, weight, bias, leak = bn
-    return ctypes.byref(_lib.BnPrologue(mean.data_ptr(), invstd.data_ptr(),
-                                        weight.data_ptr() if weight is not None else None,
-                                        bias.data_ptr() if bias is not None else None, float(leak)))
+    st = _lib.BnPrologue()
+    if bn is not None:
+        mean, invstd, weight, bias, leak = bn
+        st.mean, st.invstd = mean.data_ptr(), invstd.data_ptr()
+        st.weight = weight.data_ptr() if weight is not None else None
+        st.bias = bias.data_ptr() if bias is not None else None
+        st.leakiness = float(leak)
+    if stats is not None:
+        st.out_stats, st.out_stats_cap = stats[0].data_ptr(), stats[0].shape[0]
+        st.out_stats_rows = ctypes.pointer(stats[1])
+    return ctypes.byref(st)
+
+
+def _stats_arg(stats, n_out, cout, out):
+    """stats: None, or an empty list that receives [fp64 partials tensor, c_int rows written] of this convolution"""
+    if stats is None or n_out == 0:
+        return None
+    buf, rows = col_stats_buffer(n_out, cout, out.device)
+    stats += [buf, rows]
+    return buf, rows
+
+
+def col_stats_buffer(n_out, cout, device):
+    """-> (fp64 [cap, 2 cout] tensor, c_int) for d3d_bn_prologue.out_stats of a convolution with n_out output rows"""
+    cap = ((int(n_out) + 31) // 32) * max(1, cout // 32) + 1
+    return torch.empty((cap, 2 * cout), dtype=torch.float64, device=device), ctypes.c_int(0)
+
+
+def stats_from_partials(partials, partial_rows, rows, eps, want_invstd=True):
+    """(mean, invstd) -- or (mean, unbiased var) -- of the tensor whose producing convolution left `partials`
+    (d3d_bn_stats_from_partials): what batch_mean_invstd / batch_stats compute from the tensor itself."""
+    planes = partials.shape[1] // 2
+    mean = torch.empty(planes, dtype=torch.float32, device=partials.device)
+    other = torch.empty_like(mean)
+    nbytes = lib().d3d_bn_scratch_bytes(planes)
+    scratch = _bn_scratch(partials.device, nbytes)
+    check(lib().d3d_bn_stats_from_partials(ptr(partials), int(partial_rows), int(rows), planes, float(eps),
+                                           int(bool(want_invstd)), ptr(mean), ptr(other), ptr(scratch), scratch.numel(),
+                                           stream_of()))
+    return mean, other
 
 
 def batch_mean_invstd(features, eps):
@@ -396,7 +433,7 @@ def _conv_common(weight, packed, feats):
 
 
 def SubmanifoldConvolution_updateOutput(spatial_size, filter_size, m, input_features,
-                                        output_features, weight, bias, packed=None, residual=None, bn=None):
+                                        output_features, weight, bias, packed=None, residual=None, bn=None, stats=None):
     """sparseconvnet.h:99-105; returns the multiply-add count like the reference."""
     require_gpu(input_features, weight)
     if bias is not None and bias.numel():
@@ -412,7 +449,7 @@ def SubmanifoldConvolution_updateOutput(spatial_size, filter_size, m, input_feat
         t0 = prof.begin("subm", fv, cin, cout)
     check(lib().d3d_subm_conv_forward_dt(m._h, ints(size), ints(filt), ptr(input_features), cin, ptr(packed),
                                          cout, ptr(residual), ptr(output_features), dt, stream_of(), want,
-                                         _bn_struct(bn)))
+                                         _bn_struct(bn, _stats_arg(stats, n, cout, output_features))))
     if prof is not None:
         prof.end(t0, "subm", fv, cin, cout, n, n, macs.value, dt)
     return macs.value
@@ -443,7 +480,7 @@ def Deconvolution_prepare(input_size, output_size, filter_size, filter_stride, m
 
 
 def Convolution_updateOutput(input_size, output_size, filter_size, filter_stride, m, input_features,
-                             output_features, weight, bias, packed=None, bn=None):
+                             output_features, weight, bias, packed=None, bn=None, stats=None):
     """sparseconvnet.h:85-91."""
     require_gpu(input_features, weight)
     if bias is not None and bias.numel():
@@ -460,14 +497,15 @@ def Convolution_updateOutput(input_size, output_size, filter_size, filter_stride
     if prof is not None:
         t0 = prof.begin("conv", fv, cin, cout)
     check(lib().d3d_conv_forward_dt(m._h, ints(isz), ints(osz), ints(filt), ints(st), ptr(input_features), cin,
-                                    ptr(packed), cout, ptr(output_features), dt, stream_of(), want, _bn_struct(bn)))
+                                    ptr(packed), cout, ptr(output_features), dt, stream_of(), want,
+                                    _bn_struct(bn, _stats_arg(stats, n_out.value, cout, output_features))))
     if prof is not None:
         prof.end(t0, "conv", fv, cin, cout, input_features.shape[0], n_out.value, macs.value, dt)
     return macs.value
 
 
 def Deconvolution_updateOutput(input_size, output_size, filter_size, filter_stride, m, input_features,
-                               output_features, weight, bias, packed=None, residual=None, bn=None):
+                               output_features, weight, bias, packed=None, residual=None, bn=None, stats=None):
     """sparseconvnet.h:147-152: input = coarse, output = fine (rulebook of the matching Convolution)."""
     require_gpu(input_features, weight)
     if bias is not None and bias.numel():
@@ -483,7 +521,7 @@ def Deconvolution_updateOutput(input_size, output_size, filter_size, filter_stri
         t0 = prof.begin("deconv", fv, cin, cout)
     check(lib().d3d_deconv_forward_dt(m._h, ints(isz), ints(osz), ints(filt), ints(st), ptr(input_features),
                                       cin, ptr(packed), cout, ptr(residual), ptr(output_features), dt, stream_of(),
-                                      want, _bn_struct(bn)))
+                                      want, _bn_struct(bn, _stats_arg(stats, n, cout, output_features))))
     if prof is not None:
         prof.end(t0, "deconv", fv, cin, cout, input_features.shape[0], n, macs.value, dt)
     return macs.value

@@ -5,6 +5,8 @@ reference checkpoints load unchanged (checkpoint surface).
 Every op is a torch.autograd.Function whose forward / backward call libd3d_hip.so (the reference's
 sparseconvnet/*.py wrap the pybind calls the same way).
 """
+import os
+
 import torch
 from torch.nn import Module, Parameter
 
@@ -12,6 +14,9 @@ from . import SCN
 
 
 FUSE_BN_INTO_CONV = True   # inference only; results are bit-identical to the unfused path
+FUSE_BN_STATS = os.environ.get("D3D_FUSE_BN_STATS", "1") != "0"   # inference only: a convolution leaves the column sums of its output per row block and the
+                           # BatchNorm that follows finishes them (one small launch) instead of re-reading the tensor;
+                           # same statistics up to the fp64 summation order
 
 
 def toLongTensor(dimension, x):
@@ -76,6 +81,27 @@ class _PendingBN(SparseConvNetTensor):
         self._mat = v
 
 
+def _want_col_stats(feats):
+    """a list for the convolution to leave the column statistics of its output in (FUSE_BN_STATS), or None"""
+    return [] if (FUSE_BN_STATS and not torch.is_grad_enabled() and feats.dtype == torch.float32) else None
+
+
+def _conv_output(f, stats, metadata, spatial_size):
+    out = SparseConvNetTensor(f, metadata, spatial_size)
+    if stats and stats[1].value > 0:
+        # fp64 column sums / sums of squares per row block, the rows written, and what they describe (tensor + version)
+        out.col_partials = (stats[0], stats[1].value, f, f._version)
+    return out
+
+
+def _col_partials(input, f):
+    """the column statistics the producing convolution left for exactly this tensor, or None"""
+    cp = getattr(input, "col_partials", None)
+    if cp is not None and cp[2] is f and cp[3] == f._version and FUSE_BN_STATS:
+        return cp
+    return None
+
+
 def _conv_input(input):
     """(features to read, fused-BN tuple or None)"""
     if isinstance(input, _PendingBN) and input._mat is None and input._raw.shape[1] in (32, 64, 128, 256):
@@ -124,18 +150,18 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, feats, weight, residual, kind, metadata, in_size, out_size, filter_size, filter_stride, packed,
-                bn=None):
+                bn=None, stats=None):
         out = feats.new_empty(0)
         res = None if residual is None else residual.contiguous()
         if kind == 0:
             SCN.SubmanifoldConvolution_updateOutput(in_size, filter_size, metadata, feats, out, weight, None,
-                                                    packed=packed, residual=res, bn=bn)
+                                                    packed=packed, residual=res, bn=bn, stats=stats)
         elif kind == 1:
             SCN.Convolution_updateOutput(in_size, out_size, filter_size, filter_stride, metadata, feats, out, weight,
-                                         None, packed=packed, bn=bn)
+                                         None, packed=packed, bn=bn, stats=stats)
         else:
             SCN.Deconvolution_updateOutput(in_size, out_size, filter_size, filter_stride, metadata, feats, out,
-                                           weight, None, packed=packed, residual=res, bn=bn)
+                                           weight, None, packed=packed, residual=res, bn=bn, stats=stats)
         ctx.save_for_backward(feats, weight)
         ctx.args = (kind, metadata, in_size, out_size, filter_size, filter_stride, residual is not None)
         return out
@@ -158,7 +184,7 @@ class _ConvFn(torch.autograd.Function):
             SCN.Deconvolution_backward(in_size, out_size, filter_size, filter_stride, metadata, feats, d_in, d_out,
                                        weight, d_w, None, want_d_input=want_in)
         return (d_in if want_in else None, d_w, d_out if has_res else None, None, None, None, None, None, None, None,
-                None)
+                None, None)
 
 
 class _BatchNormFn(torch.autograd.Function):
@@ -255,10 +281,11 @@ class SubmanifoldConvolution(Module, _PackedWeightMixin):
     def forward(self, input, residual=None):
         feats, bn = _conv_input(input)
         assert feats.nelement() == 0 or feats.size(1) == SCN.stored_planes(self.nIn, feats.dtype), (self.nIn, self.nOut)
+        stats = _want_col_stats(feats)
         f = _apply(_ConvFn, feats, self.weight, None if residual is None else residual.features, 0,
                           input.metadata, input.spatial_size, input.spatial_size, self.filter_size, None,
-                          self._packed(feats.dtype), bn)
-        return SparseConvNetTensor(f, input.metadata, input.spatial_size)
+                          self._packed(feats.dtype), bn, stats)
+        return _conv_output(f, stats, input.metadata, input.spatial_size)
 
     def input_spatial_size(self, out_size):
         return out_size
@@ -283,9 +310,10 @@ class Convolution(Module, _PackedWeightMixin):
         out_size = (input.spatial_size - self.filter_size) // self.filter_stride + 1
         assert ((out_size - 1) * self.filter_stride + self.filter_size == input.spatial_size).all(), \
             (input.spatial_size, out_size, self.filter_size, self.filter_stride)
+        stats = _want_col_stats(feats)
         f = _apply(_ConvFn, feats, self.weight, None, 1, input.metadata, input.spatial_size, out_size,
-                          self.filter_size, self.filter_stride, self._packed(feats.dtype), bn)
-        return SparseConvNetTensor(f, input.metadata, out_size)
+                          self.filter_size, self.filter_stride, self._packed(feats.dtype), bn, stats)
+        return _conv_output(f, stats, input.metadata, out_size)
 
     def input_spatial_size(self, out_size):
         return (out_size - 1) * self.filter_stride + self.filter_size
@@ -308,10 +336,11 @@ class Deconvolution(Module, _PackedWeightMixin):
         feats, bn = _conv_input(input)
         assert feats.nelement() == 0 or feats.size(1) == SCN.stored_planes(self.nIn, feats.dtype)
         out_size = (input.spatial_size - 1) * self.filter_stride + self.filter_size
+        stats = _want_col_stats(feats)
         f = _apply(_ConvFn, feats, self.weight, None if residual is None else residual.features, 2,
                           input.metadata, input.spatial_size, out_size, self.filter_size, self.filter_stride,
-                          self._packed(feats.dtype), bn)
-        return SparseConvNetTensor(f, input.metadata, out_size)
+                          self._packed(feats.dtype), bn, stats)
+        return _conv_output(f, stats, input.metadata, out_size)
 
     def input_spatial_size(self, out_size):
         return (out_size - self.filter_size) // self.filter_stride + 1
@@ -337,7 +366,11 @@ class BatchNormalization(Module):
         if not (self.training or self.track_running_stats) and not torch.is_grad_enabled() and FUSE_BN_INTO_CONV:
             # inference with batch statistics (batchNormalization.py:53-55): hand (mean, invstd, gamma, beta, leak)
             # to the consuming convolution instead of writing the normalised tensor
-            mean, invstd = SCN.batch_mean_invstd(f, self.eps)
+            cp = _col_partials(input, f)
+            if cp is not None:
+                mean, invstd = SCN.stats_from_partials(cp[0], cp[1], f.shape[0], self.eps, want_invstd=True)
+            else:
+                mean, invstd = SCN.batch_mean_invstd(f, self.eps)
             return _PendingBN(f, (mean, invstd, self.weight if self.affine else None,
                                   self.bias if self.affine else None, self.leakiness), input.metadata,
                               input.spatial_size)
@@ -348,7 +381,11 @@ class BatchNormalization(Module):
         if self.training or self.track_running_stats:
             mean, var = self.running_mean, self.running_var
         else:  # batchNormalization.py:53-55: batch statistics stand in for the running ones
-            mean, var = SCN.batch_stats(f.detach())
+            cp = _col_partials(input, f) if not torch.is_grad_enabled() else None
+            if cp is not None:
+                mean, var = SCN.stats_from_partials(cp[0], cp[1], f.shape[0], self.eps, want_invstd=False)
+            else:
+                mean, var = SCN.batch_stats(f.detach())
         y = _apply(_BatchNormFn, f, self.weight if self.affine else None, self.bias if self.affine else None,
                                mean, var, self.eps, self.momentum, self.training, self.leakiness)
         return _like(input, y)

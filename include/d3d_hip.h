@@ -155,6 +155,16 @@ int d3d_pack_conv_weight(const float *w, int filter_volume, int cin, int cout, f
 typedef struct {
   const float *mean, *invstd, *weight, *bias; /* [Cin]; weight / bias may be NULL */
   float leakiness;
+  /* ... and of the statistics pass of the CONSUMER's BatchNormalization into the epilogue (fp32 storage): when
+   * out_stats != NULL the convolution also leaves, per 32-row block (per workgroup of the reduction for an offset-split
+   * launch), the fp64 sums and sums of squares of the output columns it stored: out_stats[row][2 * Cout], at most
+   * out_stats_cap rows (ceil(n_out / 32) * max(1, Cout / 32) always suffice); *out_stats_rows (host) receives the
+   * number of rows written, 0 when nothing was (bf16 storage, capacity too small).  d3d_bn_stats_from_partials turns
+   * them into the BatchNorm's statistics in a fixed summation order.  No reference counterpart: SCN/CPU/BatchNormalization.cpp:20-31
+   * makes its own pass over the tensor.                                                                             */
+  double *out_stats;
+  int out_stats_cap;
+  int *out_stats_rows;
 } d3d_bn_prologue;
 int d3d_subm_conv_forward(d3d_meta *m, const int *spatial_size_host, const int *filter_host,
                           const float *in, int cin, const float *packed_w, int cout,
@@ -192,6 +202,13 @@ int d3d_deconv_forward_dt(d3d_meta *m, const int *in_size_host, const int *out_s
  * every weight fetch in launches that keep at least min_waves * row_blocks waves (min_waves < 0: the default).
  * Results do not depend on it beyond the summation grouping of offset-split launches.                           */
 int d3d_conv_bf16_tuning(int row_blocks, long min_waves);
+/* d3d_bn_batch_stats (want_invstd == 0: mean, unbiased var) / d3d_bn_batch_invstd (want_invstd != 0: mean,
+ * powf(var + eps, -0.5)) from the column sums a convolution left per row block (d3d_bn_prologue.out_stats: partial_rows
+ * rows of [2 * planes] fp64) instead of from the tensor; `rows` = rows of the tensor.  Same arithmetic after the sums,
+ * a fixed summation order (deterministic), one launch.                                                              */
+int d3d_bn_stats_from_partials(const double *partials, int partial_rows, int rows, int planes, float eps,
+                               int want_invstd, float *mean, float *var_or_invstd, void *scratch, size_t scratch_bytes,
+                               void *stream);
 /* d3d_bn_batch_invstd / d3d_bn_apply on a tensor of the given storage type (statistics and parameters fp32). */
 int d3d_bn_batch_invstd_dt(const void *in, int rows, int planes, float eps, float *mean, float *invstd,
                            void *scratch, size_t scratch_bytes, int dtype, void *stream);

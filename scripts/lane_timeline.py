@@ -35,9 +35,11 @@ with torch.no_grad():
         end.record()
         torch.cuda.synchronize()
         marks, timeline.MARKS = timeline.MARKS, None
-        for label, k, v in marks:
-            t = (v - h0) * 1e3 if isinstance(v, float) else start.elapsed_time(v)
+        for label, k, ev, host in marks:
+            t = (host - h0) * 1e3 if ev is None else start.elapsed_time(ev)
             rows.setdefault((k, label), []).append(t)
+            if ev is not None and k < 0:
+                rows.setdefault((k, label + " [host enqueued]"), []).append((host - h0) * 1e3)
         rows.setdefault((-1, "pass done"), []).append(start.elapsed_time(end))
 labels = ["host enters", "geo starts", "geo done", "host has count", "plan starts", "plan 3x3x3 done", "plan views done",
           "main arrives", "main continues", "host leaves"]
@@ -51,4 +53,4 @@ for k in sorted({k for k, _ in rows if k >= 0}):
     print(f"{k:5d} " + " ".join(cells))
 print("caller's stream after the levels:")
 for (k, l), v in sorted(((kl, v) for kl, v in rows.items() if kl[0] < 0), key=lambda t: sorted(t[1])[len(t[1]) // 2]):
-    print(f"  {l:24s} {sorted(v)[len(v) // 2]:7.2f}")
+    print(f"  {l:40s} {sorted(v)[len(v) // 2]:7.2f}")

@@ -336,3 +336,62 @@ def test_non_finite_row_stays_local(dev, fused):
     got = conv(x).features
     bad = torch.nonzero(torch.isnan(got).any(1)).view(-1).cpu().numpy()
     assert np.array_equal(bad, touched) and 0 < len(touched) < 60
+
+
+@pytest.mark.parametrize("n_points,cin,cout", [(40000, 32, 32), (40000, 64, 64), (40000, 64, 128), (3000, 128, 128),
+                                               (600, 256, 256), (40, 128, 256)])
+def test_conv_epilogue_column_sums_give_the_batchnorm_statistics(dev, n_points, cin, cout):
+    """d3d_bn_prologue.out_stats: the per-row-block fp64 column sums a convolution leaves (unsplit launches: from k_conv's
+    epilogue; offset-split few-row launches: from k_conv_reduce), finished by d3d_bn_stats_from_partials, are the
+    statistics d3d_bn_batch_invstd / d3d_bn_batch_stats compute from the stored tensor -- fp64 sums in another order, so
+    equal after the rounding to fp32 up to 1 ulp: tolerance 5e-7 relative.  Submanifold (+ residual), strided, deconvolution."""
+    from detection_3d_amd import sparseconvnet as scn
+    from detection_3d_amd.sparseconvnet import SCN, modules
+    size = (128, 128, 32)
+    _, coords, _ = small_scene(n_points, n_points, (2.5, 2.0, 0.6), size)
+    rng = np.random.RandomState(cin + cout)
+    feats = torch.from_numpy((rng.randn(coords.shape[0], cin) * 3 + 1).astype(np.float32)).to(dev)
+    torch.manual_seed(0)
+    with torch.no_grad():
+        t = scn.InputLayer(3, size, mode=4)([torch.from_numpy(coords), feats])
+        sub = scn.SubmanifoldConvolution(3, cin, cout, 3, False).to(dev)
+        down = scn.Convolution(3, cin, cout, [2, 2, 2], [2, 2, 2], False).to(dev)
+        up = scn.Deconvolution(3, cout, cout, [2, 2, 2], [2, 2, 2], False).to(dev)
+        res = scn.SparseConvNetTensor(torch.randn(t.features.shape[0], cout, device=dev), t.metadata, t.spatial_size)
+        outs = [sub(t), sub(t, residual=res), down(t)]
+        outs.append(up(outs[2], residual=res))
+        for o in outs:
+            cp = modules._col_partials(o, o.features)
+            assert cp is not None and cp[1] > 0
+            f = o.features
+            for want_invstd, direct in ((True, SCN.batch_mean_invstd(f, 1e-4)), (False, SCN.batch_stats(f))):
+                got = SCN.stats_from_partials(cp[0], cp[1], f.shape[0], 1e-4, want_invstd=want_invstd)
+                for g, w in zip(got, direct):
+                    assert torch.isfinite(g).all()
+                    assert ((g - w).abs() <= 5e-7 * w.abs().clamp(min=1e-3)).all(), (g - w).abs().max()
+            x = f.double()
+            assert ((got[0].double() - x.mean(0)).abs() <= 1e-6 * x.abs().mean(0).clamp(min=1e-3)).all()
+        # a tensor that was modified or replaced after the convolution wrote it no longer matches its partials
+        o = outs[0]
+        o.features.add_(1.0)
+        assert modules._col_partials(o, o.features) is None
+
+
+def test_backbone_with_and_without_epilogue_statistics(dev):
+    """FUSE_BN_STATS only changes where the BatchNorm sums come from: every output map within 1e-5 of the pass that
+    re-reads the tensors (statistics equal to 1 ulp, amplified through ~20 layers), and deterministic to the bit."""
+    from detection_3d_amd.sparseconvnet import modules
+    size = (256, 256, 32)
+    _, coords, feats = small_scene(12, 50000, (5.0, 4.0, 0.6), size)
+    net = _mini_fpn(dev, True, True)
+    outs = []
+    for fused in (True, True, False):
+        modules.FUSE_BN_STATS = fused
+        try:
+            rpn, roi = net([torch.from_numpy(coords), torch.from_numpy(feats).to(dev)])
+        finally:
+            modules.FUSE_BN_STATS = True
+        outs.append([t.features.clone() for t in list(rpn) + list(roi)])
+    for a, b, c in zip(*outs):
+        assert torch.equal(a, b)
+        assert rel_err(a.cpu().numpy(), c.cpu().numpy()) < 1e-5
