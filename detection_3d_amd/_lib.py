@@ -39,6 +39,9 @@ _SIGS = {
     "d3d_post_scores": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, vp, vp, vp]),
     "d3d_post_order": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp]),
     "d3d_post_gather": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]),
+    "d3d_post_select_max": (ctypes.c_int, []),
+    "d3d_post_select": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp,
+                                       vp]),
     "d3d_roi_prepare": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_float, c_float_p, ctypes.c_int, ctypes.c_float, vp, vp,
                                        vp, vp]),
     "d3d_voxelize": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_int_p, vp, vp,

@@ -453,12 +453,13 @@ __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long *__re
     const int base = c * 64;
     return (c < ncw && lane < min(64, n - base)) ? mask[(size_t)(base + lane) * ncb + c] : 0ull;
   };
-  // one chunk: `w` holds its rows, `diag` its diagonal word; the NEXT chunk's rows and diagonal are requested
-  // before the dependent chain so that their latency hides under it
-  auto step = [&](int c, const unsigned long long *w, unsigned long long *w_next, unsigned long long &diag) {
+  // one chunk: `w` holds its rows, `diag` its diagonal word; the rows of the chunk AFTER NEXT and the next diagonal
+  // are requested before the dependent chain, so that a batch of 64 row loads has two chains to arrive under (one
+  // chain is shorter than the batch's latency; the wave is alone on its SIMD and may use all 512 VGPRs)
+  auto step = [&](int c, const unsigned long long *w, unsigned long long *w_fill, unsigned long long &diag) {
     const int base = c * 64;
     const int nrow = min(64, n - base);
-    load_rows(c + 1, w_next);
+    load_rows(c + 2, w_fill);
     const unsigned long long diag_next = load_diag(c + 1);
     // word c of the removed set, read into SGPRs: alive / kept / cnt and with them the whole chain stay scalar
     unsigned long long alive =
@@ -487,12 +488,14 @@ __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long *__re
     cnt += __popcll(kept);
     diag = diag_next;
   };
-  unsigned long long wa[64], wb[64];
+  unsigned long long wa[64], wb[64], wc[64];
   unsigned long long diag = load_diag(0);
   load_rows(0, wa);
-  for (int c = 0; c < ncw && cnt < max_keep; c += 2) {   // the caller keeps at most max_keep survivors
-    step(c, wa, wb, diag);
+  load_rows(1, wb);
+  for (int c = 0; c < ncw && cnt < max_keep; c += 3) {   // the caller keeps at most max_keep survivors
+    step(c, wa, wc, diag);
     if (c + 1 < ncw && cnt < max_keep) step(c + 1, wb, wa, diag);
+    if (c + 2 < ncw && cnt < max_keep) step(c + 2, wc, wb, diag);
   }
   if (lane == 0) *n_keep = min(cnt, max_keep);  // the last chunk may overshoot the cap
 }
@@ -638,6 +641,94 @@ __global__ __launch_bounds__(256) void k_post_gather(const int32_t *__restrict__
   s_all[t] = valid ? prob_flat[f] : -1.f;
 }
 
+// The cut to detections_per_img and the final gathers of inference.py:140-148 in ONE single-workgroup launch (what
+// followed d3d_post_gather as ~12 tensor-library launches: top-k, compare, nonzero, three index ops, remainder).
+// Candidates t = 0 .. segments * n_max - 1 (class-major, selection order): score s[t] = prob_flat[keep[t]] for
+// t % n_max < n_keep[t / n_max], else -1.  thresh = the D-th largest s (D > 0 and D < #candidates; a padding -1 when
+// fewer than D survive) clamped to >= 0; the selected set is { t : s[t] >= thresh } IN t ORDER -- like the reference's
+// `keep = cls_scores >= image_thresh`, ties at the threshold all stay.  For every selected t: the box, the score and
+// the label (box index % nc).  The D-th largest is found by a 4 x 8-bit radix select on the order-preserving integer
+// image of the floats (exact), the compaction by a workgroup scan.
+static constexpr int kSelMax = 8192, kSelThreads = 1024;
+__device__ __forceinline__ uint32_t f32_ordered(float v) {
+  const uint32_t b = __float_as_uint(v);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__global__ __launch_bounds__(kSelThreads) void k_post_select(const int32_t *__restrict__ keep,
+                                                             const int32_t *__restrict__ nk, int nseg, int n_max,
+                                                             const float *__restrict__ prob_flat,
+                                                             const float *__restrict__ boxes, int nc, int D,
+                                                             float *__restrict__ out_boxes, float *__restrict__ out_scores,
+                                                             int64_t *__restrict__ out_labels, int32_t *__restrict__ out_n) {
+  __shared__ uint32_t key[kSelMax];
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t wsum[kSelThreads / 64];
+  __shared__ uint32_t sel_prefix, sel_rank;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = nseg * n_max;
+  for (int t = tid; t < N; t += kSelThreads) {
+    const bool valid = (t % n_max) < nk[t / n_max];
+    key[t] = f32_ordered(valid ? prob_flat[keep[t]] : -1.f);
+  }
+  uint32_t thresh_key = f32_ordered(0.f);     // s >= 0: every survivor
+  if (D > 0 && D < N) {
+    // radix select of the D-th largest key: fix 8 bits per pass, most significant first
+    uint32_t prefix = 0, want = (uint32_t)D;   // `want`-th largest among the keys that match `prefix` on the fixed bits
+    for (int pass = 0; pass < 4; pass++) {
+      const int shift = 24 - 8 * pass;
+      const uint32_t fixed_mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      for (int t = tid; t < N; t += kSelThreads) {
+        const uint32_t k = key[t];
+        if ((k & fixed_mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t acc = 0;
+        int b = 255;
+        for (; b > 0; b--) {
+          if (acc + hist[b] >= want) break;
+          acc += hist[b];
+        }
+        sel_prefix = prefix | ((uint32_t)b << shift);
+        sel_rank = want - acc;
+      }
+      __syncthreads();
+      prefix = sel_prefix;
+      want = sel_rank;
+      __syncthreads();
+    }
+    thresh_key = max(prefix, thresh_key);      // thresh.clamp_min(0)
+  }
+  __syncthreads();
+  // ordered compaction: thread t owns the contiguous candidates [per * t, per * t + per)
+  const int per = (N + kSelThreads - 1) / kSelThreads;
+  const int t0 = min(N, tid * per), t1 = min(N, t0 + per);
+  uint32_t mine = 0;
+  for (int t = t0; t < t1; t++) mine += key[t] >= thresh_key;
+  uint32_t incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  uint32_t pos = incl - mine;
+  for (int w = 0; w < wave; w++) pos += wsum[w];
+  if (tid == kSelThreads - 1) *out_n = (int32_t)(pos + mine);
+  for (int t = t0; t < t1; t++) {
+    if (key[t] < thresh_key) continue;
+    const int f = keep[t];
+#pragma unroll
+    for (int j = 0; j < 7; j++) out_boxes[(size_t)pos * 7 + j] = boxes[(size_t)f * 7 + j];
+    out_scores[pos] = prob_flat[f];
+    out_labels[pos] = (int64_t)(f % nc);
+    pos++;
+  }
+}
+
 int d3d_post_scores(const float *prob, int K, int nc, float thresh, float *sc, int32_t *counts, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   D3D_REQUIRE(K >= 0 && nc >= 2, "post_scores: bad shape");
@@ -667,6 +758,25 @@ int d3d_post_gather(const int32_t *keep, const int32_t *n_keep, int segments, in
   D3D_REQUIRE(keep && n_keep && prob_flat && scores && flat, "post_gather: null pointer");
   hipLaunchKernelGGL(k_post_gather, dim3((segments * n_max + 255) / 256), dim3(256), 0, s, keep, n_keep, segments, n_max,
                      prob_flat, scores, flat);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+int d3d_post_select_max(void) { return kSelMax; }
+int d3d_post_select(const int32_t *keep, const int32_t *n_keep, int segments, int n_max, const float *prob_flat,
+                    const float *boxes, int nc, int detections, float *out_boxes, float *out_scores, int64_t *out_labels,
+                    int32_t *out_n, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(segments >= 0 && n_max >= 0 && nc >= 1 && out_n, "post_select: bad arguments");
+  const long N = (long)segments * n_max;
+  D3D_REQUIRE(N <= kSelMax, "post_select: %ld candidates exceed the %d of the single-workgroup selection", N, kSelMax);
+  if (N == 0) {
+    D3D_HIP_CHECK(hipMemsetAsync(out_n, 0, sizeof(int32_t), s));
+    return D3D_OK;
+  }
+  D3D_REQUIRE(keep && n_keep && prob_flat && boxes && out_boxes && out_scores && out_labels, "post_select: null pointer");
+  hipLaunchKernelGGL(k_post_select, dim3(1), dim3(kSelThreads), 0, s, keep, n_keep, segments, n_max, prob_flat, boxes, nc,
+                     detections, out_boxes, out_scores, out_labels, out_n);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }

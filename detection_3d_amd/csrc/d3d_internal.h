@@ -235,4 +235,43 @@ __device__ __forceinline__ int hash_find(const HashEntry *__restrict__ tab, int 
   }
 }
 
+// hash_find for N independent keys of a lane in lockstep: every probe round issues the N slot loads together, so the
+// round trips of the keys overlap instead of following one another (each hash_find is a loop of its own, which the
+// compiler does not interleave with the next one).  out[i] = site id or -1; keys with want[i] == false give -1.
+template <int N>
+__device__ __forceinline__ void hash_find_n(const HashEntry *__restrict__ tab, int cap, const uint64_t (&key)[N],
+                                            const bool (&want)[N], int (&out)[N]) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  uint32_t slot[N], round[N];
+  bool live[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    slot[i] = hash_key(key[i]) & (uint32_t)(cap - 1);
+    round[i] = 0;
+    live[i] = want[i];
+    out[i] = -1;
+  }
+  while (true) {
+    u32x4 e[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) e[i] = *(const u32x4 *)&tab[live[i] ? slot[i] : 0u];   // unconditional: no branch per key
+    bool more = false;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      if (!live[i]) continue;
+      const uint64_t k = ((uint64_t)e[i][1] << 32) | e[i][0];
+      if (k == key[i]) {
+        out[i] = (int)e[i][2];
+        live[i] = false;
+      } else if (k == kEmptyKey) {
+        live[i] = false;
+      } else {
+        slot[i] = probe_next(slot[i], round[i], cap);
+        more = true;
+      }
+    }
+    if (!more) break;
+  }
+}
+
 }  // namespace d3d

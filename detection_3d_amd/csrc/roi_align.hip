@@ -168,22 +168,36 @@ __global__ __launch_bounds__(kRoiWaves * 64) void k_roi_sparse(
       const int zb = corner >> 2, yb = (corner >> 1) & 1, xb = corner & 1;
       int row[kRoiG];
       float wgt[kRoiG];
+      // the probes of a lane four bins at a time in lockstep (hash_find_n: their round trips overlap; all kRoiG at
+      // once costs a wave of occupancy in registers)
+      static_assert(kRoiG % 4 == 0, "probe groups of four");
 #pragma unroll
-      for (int gi = 0; gi < kRoiG; gi++) {
-        const int bin = b0 + gi;
-        row[gi] = -1;
-        wgt[gi] = 0.f;
-        if (s < NS && bin < NB) {
-          const int pz = bin % PZ, pw = (bin / PZ) % PW, ph = bin / (PZ * PW);
-          float y, x, z;
-          sample_pos(g, ph, pw, pz, iy, ix, iz, y, x, z);
-          Tri t;
-          if (tri_setup(y, x, z, H, W, Z, t)) {
-            wgt[gi] = (yb ? t.ly : t.hy) * (xb ? t.lx : t.hx) * (zb ? t.lz : t.hz);
-            // dense index [y][x][z]: y runs over the tensor's 1st spatial axis, x over the 2nd
-            row[gi] = hash_find(tab, cap, pack_key(g.b, yb ? t.yh : t.yl, xb ? t.xh : t.xl, zb ? t.zh : t.zl));
+      for (int g0 = 0; g0 < kRoiG; g0 += 4) {
+        uint64_t key[4];
+        bool want[4];
+        int r4[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int bin = b0 + g0 + j;
+          wgt[g0 + j] = 0.f;
+          key[j] = 0;
+          want[j] = false;
+          if (s < NS && bin < NB) {
+            const int pz = bin % PZ, pw = (bin / PZ) % PW, ph = bin / (PZ * PW);
+            float y, x, z;
+            sample_pos(g, ph, pw, pz, iy, ix, iz, y, x, z);
+            Tri t;
+            if (tri_setup(y, x, z, H, W, Z, t)) {
+              wgt[g0 + j] = (yb ? t.ly : t.hy) * (xb ? t.lx : t.hx) * (zb ? t.lz : t.hz);
+              // dense index [y][x][z]: y runs over the tensor's 1st spatial axis, x over the 2nd
+              key[j] = pack_key(g.b, yb ? t.yh : t.yl, xb ? t.xh : t.xl, zb ? t.zh : t.zl);
+              want[j] = true;
+            }
           }
         }
+        hash_find_n<4>(tab, cap, key, want, r4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) row[g0 + j] = r4[j];
       }
       // the 64 taps of a bin fall into a handful of cells (its sub-samples are a fraction of a cell apart): merge
       // the taps of one cell (weights summed by a wave butterfly) so that each feature row is fetched once per bin

@@ -130,10 +130,12 @@ class AnchorGenerator(nn.Module):
         ns = [f.features.shape[0] for f in feature_maps_sparse]
         out = torch.empty((sum(ns) * A, 7), dtype=torch.float32, device=feature_maps_sparse[0].features.device)
         o = 0
-        for base, fmap, stride, n in zip(self.cell_anchors, feature_maps_sparse, self.strides, ns):
+        lists = getattr(self, "_anchor_lists", None)
+        if lists is None:       # host copies of the (constant) cell anchors and strides, made once
+            lists = self._anchor_lists = [(b.tolist(), st.tolist()) for b, st in zip(self.cell_anchors, self.strides)]
+        for (base, stride), fmap, n in zip(lists, feature_maps_sparse, ns):
             if n:
-                fmap.metadata.anchors(fmap.spatial_size, base.tolist(), stride.tolist(), self.voxel_scale,
-                                      out[o * A:(o + n) * A])
+                fmap.metadata.anchors(fmap.spatial_size, base, stride, self.voxel_scale, out[o * A:(o + n) * A])
             o += n
         return out
 
@@ -478,6 +480,15 @@ class FPNPredictor(nn.Module):
         return self.cls_score(x), self.bbox_pred(x)
 
 
+_POST_SELECT_CAP = []
+
+
+def _POST_SELECT_MAX():
+    if not _POST_SELECT_CAP:
+        _POST_SELECT_CAP.append(int(lib().d3d_post_select_max()))
+    return _POST_SELECT_CAP[0]
+
+
 class PostProcessor(nn.Module):
     """roi_heads/box_head_3d/inference.py:40-149."""
 
@@ -511,8 +522,21 @@ class PostProcessor(nn.Module):
         n_max = min(K, 2000)                                                     # pre_max_size of rotate_nms_3d
         keep, nk = box_ops.nms_3d_batched(boxes.view(-1, 7), order, counts, n_max, self.nms, self.nms_aug_thickness,
                                           500)                                   # post_max_size (boxlist_ops_3d.py)
-        s_all = torch.empty(((nc - 1) * n_max,), dtype=torch.float32, device=dev)
-        flat_all = torch.empty(((nc - 1) * n_max,), dtype=torch.int64, device=dev)
+        N = (nc - 1) * n_max
+        if N <= _POST_SELECT_MAX():
+            # the cut to detections_per_img and the final gathers in one launch (d3d_post_select), one read-back
+            out_b = torch.empty((N, 7), dtype=torch.float32, device=dev)
+            out_s = torch.empty((N,), dtype=torch.float32, device=dev)
+            out_l = torch.empty((N,), dtype=torch.int64, device=dev)
+            out_n = torch.empty((1,), dtype=torch.int32, device=dev)
+            boxes = boxes.contiguous()
+            check(lib().d3d_post_select(ptr(keep), ptr(nk), nc - 1, n_max, ptr(prob), ptr(boxes), nc,
+                                        int(self.detections_per_img), ptr(out_b), ptr(out_s), ptr(out_l), ptr(out_n),
+                                        stream_of()))
+            n = int(out_n.item())                                                # the one host synchronisation
+            return {"bbox3d": out_b[:n], "scores": out_s[:n], "labels": out_l[:n]}
+        s_all = torch.empty((N,), dtype=torch.float32, device=dev)
+        flat_all = torch.empty((N,), dtype=torch.int64, device=dev)
         check(lib().d3d_post_gather(ptr(keep), ptr(nk), nc - 1, n_max, ptr(prob), ptr(s_all), ptr(flat_all), stream_of()))
         if 0 < self.detections_per_img < s_all.shape[0]:                         # :140-148 without a second read-back:
             # the D-th largest score; with fewer than D survivors it is a padding entry (-1) and every survivor stays

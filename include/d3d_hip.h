@@ -354,6 +354,16 @@ int d3d_post_scores(const float *prob, int K, int nc, float thresh, float *sc, i
 int d3d_post_order(const int64_t *idx, int K, int nc, int32_t *order, void *stream);
 int d3d_post_gather(const int32_t *keep, const int32_t *n_keep, int segments, int n_max, const float *prob_flat,
                     float *scores, int64_t *flat, void *stream);
+/* post_select: post_gather, the cut to `detections` per image and the final gathers of :140-148 in one launch.  Over the
+ * candidates t (class-major, selection order) with score s[t] = prob_flat[keep[t]] (survivors) or -1 (padding): thresh =
+ * the detections-th largest s when 0 < detections < segments * n_max, clamped to >= 0, else 0; every t with
+ * s[t] >= thresh is kept IN t ORDER (ties at the threshold all stay, like `cls_scores >= image_thresh`, :146) and
+ * out_boxes [n,7] = boxes[keep[t]], out_scores [n] = s[t], out_labels int64 [n] = keep[t] % nc, *out_n (device) = n.
+ * Output capacity: segments * n_max rows.  segments * n_max <= d3d_post_select_max().                                */
+int d3d_post_select_max(void);
+int d3d_post_select(const int32_t *keep, const int32_t *n_keep, int segments, int n_max, const float *prob_flat,
+                    const float *boxes, int nc, int detections, float *out_boxes, float *out_scores, int64_t *out_labels,
+                    int32_t *out_n, void *stream);
 /* a14. BoxCoder3D.decode (maskrcnn_benchmark/modeling/box_coder_3d.py:38-65). */
 int d3d_box_decode(const float *enc, const float *anchors, int n, const float *weights_host,
                    float clip, float *out, void *stream);

@@ -1,37 +1,32 @@
-"""Development probe: cProfile of the host side of the inference step (where does Python time go?)."""
-import cProfile, pstats, sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""Host side of one building's pass: cProfile over 20 passes (sorted by own time) -- which Python / ctypes calls the
+launch thread spends its time in.  python scripts/host_profile.py [points]"""
+import cProfile, os, pstats, sys
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
 from detection_3d_amd.config import get_cfg
 from detection_3d_amd.detector import build_detection_model
 from detection_3d_amd.synthetic import make_scene
 from detection_3d_amd.voxelize import voxelize
 
+n_points = int(sys.argv[1]) if len(sys.argv) > 1 else 500000
 dev = torch.device("cuda:0")
 cfg = get_cfg("4c_Fpn432")
 torch.manual_seed(0)
 model = build_detection_model(cfg).to(dev).eval()
-scenes = [torch.from_numpy(make_scene(i, 500000)).to(dev) for i in range(2)]
+clouds = [torch.from_numpy(make_scene(i, n_points)).to(dev) for i in range(4)]
 
 
-def step(i):
-    coords, feats = voxelize(scenes[i % 2], cfg.SPARSE3D.VOXEL_SCALE, cfg.SPARSE3D.VOXEL_FULL_SCALE)
-    return model([coords, feats])
+def run(n):
+    with torch.no_grad():
+        for i in range(n):
+            model(list(voxelize(clouds[i % 4], 50, cfg.SPARSE3D.VOXEL_FULL_SCALE)))
+    torch.cuda.synchronize()
 
 
-for i in range(4):
-    step(i)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for i in range(20):
-    step(i)
-torch.cuda.synchronize()
-print("ms/step without profiler hooks: %.3f" % ((time.perf_counter() - t0) / 20 * 1e3))
+run(8)
 pr = cProfile.Profile()
 pr.enable()
-for i in range(10):
-    step(i)
-torch.cuda.synchronize()
+run(20)
 pr.disable()
 st = pstats.Stats(pr)
 st.sort_stats("tottime").print_stats(45)

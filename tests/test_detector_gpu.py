@@ -227,3 +227,43 @@ def test_post_processing_glue_launches_equal_the_tensor_op_chain(setup, dev):
         for k in ("bbox3d", "scores", "labels"):
             assert got[k].shape == want[k].shape and torch.equal(got[k], want[k]), (scale, thresh, k)
     assert post(logits, reg, mid["proposals"])["bbox3d"].shape[0] > 0
+
+
+@pytest.mark.parametrize("nseg,n_max,D", [(1, 1, 1), (3, 1000, 200), (4, 700, 100), (2, 50, 200), (8, 1024, 200), (3, 1000, 0),
+                                          (5, 333, 1)])
+def test_post_select_against_numpy(dev, nseg, n_max, D):
+    """d3d_post_select (the cut to detections_per_img + final gathers, box_head_3d/inference.py:140-148) against the same
+    selection in numpy: bit-exact rows in the same order, with scores quantised so that ties sit on the threshold (all
+    of them stay), segments that kept nothing, fewer survivors than D (the threshold is then a padding entry), D = 0."""
+    from detection_3d_amd._lib import check, lib, ptr, stream_of
+    rng = np.random.RandomState(nseg * 1000 + n_max + D)
+    nbox, nc = nseg * n_max * 2 + 3, nseg + 1
+    prob = (np.round(rng.rand(nbox) * 40) / 40 + 0.0125).astype(np.float32)
+    boxes = rng.randn(nbox, 7).astype(np.float32)
+    nk = rng.randint(0, n_max + 1, nseg).astype(np.int32)
+    nk[rng.randint(nseg)] = 0
+    if (nseg, n_max) == (2, 50):
+        nk[:] = [30, 20]                                   # 50 survivors < D
+    keep = rng.randint(0, nbox, (nseg, n_max)).astype(np.int32)
+    valid = np.arange(n_max)[None, :] < nk[:, None]
+    s = np.where(valid, prob[keep], np.float32(-1)).ravel()
+    flat = np.where(valid, keep, 0).ravel()
+    thresh = max(np.sort(s)[::-1][D - 1], np.float32(0)) if 0 < D < s.size else np.float32(0)
+    sel = s >= thresh
+    want_b, want_s, want_l = boxes[flat[sel]], prob[flat[sel]], (flat[sel] % nc).astype(np.int64)
+    N = nseg * n_max
+    t = lambda a: torch.from_numpy(a).to(dev)
+    out_b = torch.full((N, 7), float("nan"), device=dev)
+    out_s = torch.full((N,), float("nan"), device=dev)
+    out_l = torch.full((N,), -7, dtype=torch.int64, device=dev)
+    out_n = torch.full((1,), -1, dtype=torch.int32, device=dev)
+    k_, nk_, p_, b_ = t(keep), t(nk), t(prob), t(boxes)
+    check(lib().d3d_post_select(ptr(k_), ptr(nk_), nseg, n_max, ptr(p_), ptr(b_), nc, D, ptr(out_b), ptr(out_s), ptr(out_l),
+                                ptr(out_n), stream_of()))
+    n = int(out_n.item())
+    assert n == int(sel.sum())
+    assert np.array_equal(out_b[:n].cpu().numpy(), want_b)            # bit-exact
+    assert np.array_equal(out_s[:n].cpu().numpy(), want_s)
+    assert np.array_equal(out_l[:n].cpu().numpy(), want_l)
+    if 0 < D < s.size and int((s >= 0).sum()) >= D:
+        assert n >= D                                                 # ties on the threshold all stay
