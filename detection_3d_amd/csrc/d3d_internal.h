@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/d3d_hip.h"
@@ -147,7 +148,12 @@ struct d3d_meta {
   int iota_n = 0;
   // pinned host words for size read-backs
   long *host_words = nullptr;
+  // the three maps above may be read by the caller's thread while the geometry thread (d3d_geometry_async_start) adds
+  // to them: every lookup / insertion holds `mu` (map nodes do not move, so the pointers handed out stay valid)
+  std::recursive_mutex mu;
+  void *geo_async = nullptr;       // grid.hip GeoAsync: the running / last geometry chain of this metadata
 };
+#define D3D_LOCK(m) std::lock_guard<std::recursive_mutex> d3d_lock_(m->mu)
 
 namespace d3d {
 

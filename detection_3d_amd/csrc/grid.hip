@@ -2,8 +2,13 @@
 // grids, submanifold / strided rulebooks ("plans"), spatial locations, sparse->dense.
 // Replaces the single-threaded CPU rule builders of SCN/Metadata/* (see include/d3d_hip.h).
 #include <algorithm>
+#include <array>
 #include <climits>
+#include <condition_variable>
 #include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
 
 #include <hip/hip_runtime.h>
 
@@ -809,9 +814,10 @@ int plan_rules(d3d_meta *m, Plan &p, hipStream_t s, long *out) {
                        p.nbrT, total, cnt);
     D3D_LAUNCH_CHECK();
     A.used = mark;
-    D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[0], cnt, sizeof(long), hipMemcpyDeviceToHost, s));
+    // (a pinned word of its own: the geometry thread may be reading a site count back at the same time)
+    D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[8], cnt, sizeof(long), hipMemcpyDeviceToHost, s));
     D3D_HIP_CHECK(hipStreamSynchronize(s));
-    p.n_rules = m->host_words[0];
+    p.n_rules = m->host_words[8];
   }
   *out = p.n_rules;
   return D3D_OK;
@@ -838,6 +844,7 @@ static PlanKey make_key(int kind, const int *in_size, const int *filt, const int
   return k;
 }
 const Plan *find_plan(d3d_meta *m, int kind, const int *in_size, const int *filt, const int *stride) {
+  D3D_LOCK(m);
   auto it = m->plans.find(make_key(kind, in_size, filt, stride));
   return it == m->plans.end() ? nullptr : &it->second;
 }
@@ -845,10 +852,18 @@ const Plan *find_plan(d3d_meta *m, int kind, const int *in_size, const int *filt
 int get_deconv_plan(d3d_meta *m, const int *fine_size, const int *filt, const int *stride,
                     hipStream_t s, const Plan **out) {
   PlanKey key = make_key(2, fine_size, filt, stride);
-  auto it = m->plans.find(key);
-  if (it == m->plans.end()) {
-    auto raw = m->strided_raw.find(make_key(1, fine_size, filt, stride));
-    if (raw == m->strided_raw.end()) {
+  std::map<PlanKey, Plan>::iterator it;
+  std::map<PlanKey, StridedRaw>::iterator raw;
+  bool have, have_raw;
+  {
+    D3D_LOCK(m);
+    it = m->plans.find(key);
+    have = it != m->plans.end();
+    raw = m->strided_raw.find(make_key(1, fine_size, filt, stride));
+    have_raw = raw != m->strided_raw.end();
+  }
+  if (!have) {
+    if (!have_raw) {
       set_error("deconvolution: no strided rulebook for this (size, filter, stride); run the "
                 "matching convolution (d3d_conv_prepare) first");
       return D3D_ERR_STATE;
@@ -857,6 +872,7 @@ int get_deconv_plan(d3d_meta *m, const int *fine_size, const int *filt, const in
     int K = filt[0] * filt[1] * filt[2];
     int rc = finalize_plan(m, raw->second.nbr_dec, raw->second.n_in, K, p, s, nullptr);
     if (rc) return rc;
+    D3D_LOCK(m);
     auto go = m->grids.find(raw->second.out_size);
     p.n_in = go == m->grids.end() ? 0 : go->second.n;   // gathers from the coarse tensor
     it = m->plans.emplace(key, p).first;
@@ -1018,6 +1034,40 @@ __global__ void k_vox_write(const float *__restrict__ pcl, int n, int nfeat, dou
 
 using namespace d3d;
 
+namespace d3d {
+// The chain of strided grids of one scene, run by a thread of its own (d3d_geometry_async_start): every new grid costs
+// one blocking read-back of its site count, and a caller that builds the chain itself cannot enqueue feature kernels
+// while it waits.  The thread builds the listed rulebooks in order on the geometry stream and publishes, per entry,
+// the output site count and an event; the caller picks an entry up when it needs it (d3d_geometry_async_wait).
+struct GeoAsync {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<std::array<int, 12>> specs;   // in_size, out_size, filter, stride
+  std::vector<int> n_out;
+  std::vector<hipEvent_t> ev;               // pool, reused from scene to scene
+  int done = 0, rc = 0, device = 0;
+  bool running = false;
+  std::string err;
+  hipStream_t stream = nullptr;
+};
+static void geo_async_join(d3d_meta *m) {
+  GeoAsync *g = (GeoAsync *)m->geo_async;
+  if (g && g->running) {
+    if (g->th.joinable()) g->th.join();
+    g->running = false;
+  }
+}
+static void geo_async_free(d3d_meta *m) {
+  GeoAsync *g = (GeoAsync *)m->geo_async;
+  if (!g) return;
+  geo_async_join(m);
+  for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
+  delete g;
+  m->geo_async = nullptr;
+}
+}  // namespace d3d
+
 extern "C" {
 
 const char *d3d_last_error(void) { return d3d::g_err; }
@@ -1048,6 +1098,7 @@ int d3d_meta_create(d3d_meta **out, size_t arena_bytes) {
 }
 int d3d_meta_destroy(d3d_meta *m) {
   if (!m) return D3D_OK;
+  geo_async_free(m);
   (void)hipFree(m->arena.base);
   (void)hipHostFree(m->host_words);
   delete m;
@@ -1055,6 +1106,8 @@ int d3d_meta_destroy(d3d_meta *m) {
 }
 int d3d_meta_clear(d3d_meta *m) {
   D3D_REQUIRE(m, "null metadata");
+  geo_async_join(m);
+  D3D_LOCK(m);
   m->arena.used = 0;
   m->feat_arena.used = 0;
   m->feat_arena.cap = m->feat_cap_full;
@@ -1143,9 +1196,12 @@ int d3d_input_layer_build(d3d_meta *m, const int64_t *coords, int n, int ncols, 
   D3D_REQUIRE(ncols == 3 || ncols == 4, "coords must be [n,3] or [n,4], got %d columns", ncols);
   D3D_REQUIRE(mode == 3 || mode == 4, "input layer mode %d not supported (3=sum, 4=mean)", mode);
   D3D_REQUIRE(n >= 0 && (n == 0 || coords), "bad coords");
-  if (!m->grids.empty()) {
-    set_error("input layer: metadata already holds grids; call d3d_meta_clear first");
-    return D3D_ERR_STATE;
+  {
+    D3D_LOCK(m);
+    if (!m->grids.empty()) {
+      set_error("input layer: metadata already holds grids; call d3d_meta_clear first");
+      return D3D_ERR_STATE;
+    }
   }
   for (int d = 0; d < 3; d++) D3D_REQUIRE(size[d] > 0 && size[d] <= 32768, "spatial size out of range");
   Arena &A = m->arena;
@@ -1190,7 +1246,10 @@ int d3d_input_layer_build(d3d_meta *m, const int64_t *coords, int n, int ncols, 
   }
   g.n = n_active;
   m->in_active = n_active;
-  m->grids[Size3{size[0], size[1], size[2]}] = g;
+  {
+    D3D_LOCK(m);
+    m->grids[Size3{size[0], size[1], size[2]}] = g;
+  }
   *n_active_host = n_active;
   return D3D_OK;
 }
@@ -1204,8 +1263,12 @@ namespace d3d {
 int ensure_point_lists(d3d_meta *m, hipStream_t s) {
   if (m->in_lists || m->in_n == 0) return D3D_OK;
   const int n = m->in_n, n_active = m->in_active;
-  auto it = m->grids.find(m->in_size);
-  D3D_REQUIRE(it != m->grids.end(), "input layer: grid not found");
+  std::map<Size3, Grid>::iterator it;
+  {
+    D3D_LOCK(m);
+    it = m->grids.find(m->in_size);
+    D3D_REQUIRE(it != m->grids.end(), "input layer: grid not found");
+  }
   Arena &A = lane_arena(m, s);
   size_t mark = A.used;
   D3D_ALLOC(psite, uint32_t, A, n);
@@ -1282,6 +1345,7 @@ int d3d_input_layer_export(d3d_meta *m, int32_t *offsets, int32_t *idx, void *st
 }
 
 static Grid *find_grid(d3d_meta *m, const int *size) {
+  D3D_LOCK(m);
   auto it = m->grids.find(Size3{size[0], size[1], size[2]});
   return it == m->grids.end() ? nullptr : &it->second;
 }
@@ -1335,8 +1399,14 @@ int d3d_subm_prepare(d3d_meta *m, const int *size, const int *filt, void *stream
   hipStream_t s = (hipStream_t)stream;
   D3D_REQUIRE(m && size && filt, "null argument");
   PlanKey key = make_key(0, size, filt, nullptr);
-  auto it = m->plans.find(key);
-  if (it == m->plans.end()) {
+  std::map<PlanKey, Plan>::iterator it;
+  bool have;
+  {
+    D3D_LOCK(m);
+    it = m->plans.find(key);
+    have = it != m->plans.end();
+  }
+  if (!have) {
     Grid *g = find_grid(m, size);
     if (!g) {
       set_error("submanifold rulebook: no grid of spatial size [%d,%d,%d]", size[0], size[1], size[2]);
@@ -1383,6 +1453,7 @@ int d3d_subm_prepare(d3d_meta *m, const int *size, const int *filt, void *stream
       if (rc) return rc;
     }
     p.n_in = g->n;
+    D3D_LOCK(m);
     it = m->plans.emplace(key, p).first;
   }
   if (n_rules_host) return plan_rules(m, it->second, s, n_rules_host);
@@ -1394,8 +1465,14 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
   hipStream_t s = (hipStream_t)stream;
   D3D_REQUIRE(m && in_size && out_size && filt && stride, "null argument");
   PlanKey key = make_key(1, in_size, filt, stride);
-  auto it = m->plans.find(key);
-  if (it == m->plans.end()) {
+  std::map<PlanKey, Plan>::iterator it;
+  bool have;
+  {
+    D3D_LOCK(m);
+    it = m->plans.find(key);
+    have = it != m->plans.end();
+  }
+  if (!have) {
     if (int rc = check_build_stream(m, s, "strided rulebook")) return rc;
     Grid *gi = find_grid(m, in_size);
     if (!gi) {
@@ -1452,9 +1529,9 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
       hipLaunchKernelGGL(k_conv_grid_small, dim3(1), dim3(1024), 0, s, gi->loc, (int)n_entries, geo, K, n_in, tab, go.cap,
                          loc_out, nbr_fwd, nbr_dec, total);
       D3D_LAUNCH_CHECK();
-      D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[0], total, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[1], total, sizeof(int32_t), hipMemcpyDeviceToHost, s));
       D3D_HIP_CHECK(hipStreamSynchronize(s));
-      n_out = (int)*(int32_t *)&m->host_words[0];
+      n_out = (int)*(int32_t *)&m->host_words[1];
       A.used = mark;
       int rc = finalize_plan(m, nbr_fwd, n_out, K, p, s, nullptr);
       if (rc) return rc;
@@ -1478,9 +1555,9 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
       int rc = scan_exclusive_i32(flag, rank, (int)n_entries, total, A, s);
       if (rc) return rc;
       hipLaunchKernelGGL(k_conv_assign, grid1d(n_entries), dim3(256), 0, s, gi->loc, n_entries, geo, eslot, flag, rank, tab, loc_out);
-      D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[0], total, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[1], total, sizeof(int32_t), hipMemcpyDeviceToHost, s));
       D3D_HIP_CHECK(hipStreamSynchronize(s));
-      n_out = (int)*(int32_t *)&m->host_words[0];
+      n_out = (int)*(int32_t *)&m->host_words[1];
       D3D_HIP_CHECK(fill_ones(nbr_fwd, sizeof(int32_t) * ((size_t)n_out * K + 1), s));
       hipLaunchKernelGGL(k_conv_fill, grid1d(n_entries), dim3(256), 0, s, gi->loc, n_entries, geo, K, eslot, tab, nbr_fwd, nbr_dec);
       D3D_LAUNCH_CHECK();
@@ -1492,6 +1569,7 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
       if (rc) return rc;
     }
     go.n = n_out;
+    D3D_LOCK(m);   // the finished grid, raw table and rulebook become visible together
     m->grids[Size3{out_size[0], out_size[1], out_size[2]}] = go;
     StridedRaw raw;
     raw.nbr_dec = nbr_dec;
@@ -1503,6 +1581,83 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
   }
   if (n_out_host) *n_out_host = it->second.n_rows;
   if (n_rules_host) return plan_rules(m, it->second, s, n_rules_host);
+  return D3D_OK;
+}
+
+int d3d_geometry_async_start(d3d_meta *m, const int *specs, int n, void *stream) {
+  D3D_REQUIRE(m && (n == 0 || specs) && n >= 0 && n <= 64, "geometry_async_start: bad arguments");
+  D3D_REQUIRE(m->geo_locked && (hipStream_t)stream == m->geo_stream,
+              "geometry_async_start: `stream` must be the metadata's geometry stream (d3d_meta_set_geometry_stream)");
+  geo_async_join(m);
+  GeoAsync *g = (GeoAsync *)m->geo_async;
+  if (!g) m->geo_async = g = new GeoAsync();
+  g->specs.resize(n);
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < 12; j++) g->specs[i][j] = specs[i * 12 + j];
+  g->n_out.assign(n, 0);
+  while ((int)g->ev.size() < n) {
+    hipEvent_t e;
+    D3D_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    g->ev.push_back(e);
+  }
+  g->done = 0;
+  g->rc = D3D_OK;
+  g->err.clear();
+  g->stream = (hipStream_t)stream;
+  D3D_HIP_CHECK(hipGetDevice(&g->device));
+  if (n == 0) return D3D_OK;
+  g->running = true;
+  g->th = std::thread([m, g]() {
+    int rc = hipSetDevice(g->device) == hipSuccess ? D3D_OK : D3D_ERR_HIP;
+    if (rc) set_error("geometry thread: hipSetDevice(%d) failed", g->device);
+    const int n = (int)g->specs.size();
+    for (int i = 0; i < n && rc == D3D_OK; i++) {
+      const int *sp = g->specs[i].data();
+      int n_out = 0;
+      rc = d3d_conv_prepare(m, sp, sp + 3, sp + 6, sp + 9, g->stream, &n_out, nullptr);
+      if (rc == D3D_OK && hipEventRecord(g->ev[i], g->stream) != hipSuccess) {
+        set_error("geometry thread: hipEventRecord failed");
+        rc = D3D_ERR_HIP;
+      }
+      std::lock_guard<std::mutex> lk(g->mu);
+      if (rc == D3D_OK) {
+        g->n_out[i] = n_out;
+        g->done = i + 1;
+      } else {
+        g->rc = rc;
+        g->err = d3d_last_error();
+      }
+      g->cv.notify_all();
+    }
+  });
+  return D3D_OK;
+}
+
+int d3d_geometry_async_wait(d3d_meta *m, int index, int *n_out_host, void *wait_stream) {
+  D3D_REQUIRE(m && m->geo_async, "geometry_async_wait: no chain was started");
+  GeoAsync *g = (GeoAsync *)m->geo_async;
+  D3D_REQUIRE(index >= 0 && index < (int)g->specs.size(), "geometry_async_wait: entry %d of %d", index, (int)g->specs.size());
+  {
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->cv.wait(lk, [&] { return g->done > index || g->rc != D3D_OK; });
+    if (g->done <= index) {
+      set_error("geometry thread: %s", g->err.c_str());
+      return g->rc;
+    }
+    if (n_out_host) *n_out_host = g->n_out[index];
+  }
+  if (wait_stream != (void *)g->stream) D3D_HIP_CHECK(hipStreamWaitEvent((hipStream_t)wait_stream, g->ev[index], 0));
+  return D3D_OK;
+}
+
+int d3d_geometry_async_finish(d3d_meta *m) {
+  D3D_REQUIRE(m, "null metadata");
+  geo_async_join(m);
+  GeoAsync *g = (GeoAsync *)m->geo_async;
+  if (g && g->rc != D3D_OK) {
+    set_error("geometry thread: %s", g->err.c_str());
+    return g->rc;
+  }
   return D3D_OK;
 }
 
@@ -1528,7 +1683,7 @@ int d3d_export_rules(d3d_meta *m, int kind, const int *in_size, const int *filt,
   }
   *n_host = 0;
   if (p->n_rows == 0) return D3D_OK;
-  Arena &A = m->arena;
+  Arena &A = lane_arena(m, s);
   size_t mark = A.used;
   D3D_ALLOC(cnt, unsigned long long, A, 1);
   D3D_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), s));
@@ -1536,9 +1691,9 @@ int d3d_export_rules(d3d_meta *m, int kind, const int *in_size, const int *filt,
   // kind 2 (deconvolution plan): rows are fine sites = the rule's "in" side of the strided conv
   hipLaunchKernelGGL(k_export_plan, grid1d((long)npos * p->K), dim3(256), 0, s, p->nbrT, p->rows, npos, p->K, kind == 2 ? 1 : 0, triples, capacity, cnt);
   D3D_LAUNCH_CHECK();
-  D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[0], cnt, sizeof(long), hipMemcpyDeviceToHost, s));
+  D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[9], cnt, sizeof(long), hipMemcpyDeviceToHost, s));
   D3D_HIP_CHECK(hipStreamSynchronize(s));
-  *n_host = m->host_words[0];
+  *n_host = m->host_words[9];
   A.used = mark;
   return D3D_OK;
 }

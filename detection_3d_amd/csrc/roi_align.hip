@@ -452,8 +452,14 @@ int d3d_roi_align_rotated_3d_sparse_forward(d3d_meta *m, const int *size, const 
                                             float *out, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   D3D_REQUIRE(m && size && C > 0 && K >= 0 && ph > 0 && pw > 0 && pz > 0, "roi_align_sparse: bad arguments");
-  auto it = m->grids.find(Size3{size[0], size[1], size[2]});
-  if (it == m->grids.end()) {
+  std::map<Size3, Grid>::iterator it;
+  bool have_grid;
+  {
+    D3D_LOCK(m);
+    it = m->grids.find(Size3{size[0], size[1], size[2]});
+    have_grid = it != m->grids.end();
+  }
+  if (!have_grid) {
     set_error("roi_align_sparse: no grid of spatial size [%d,%d,%d]", size[0], size[1], size[2]);
     return D3D_ERR_STATE;
   }
@@ -497,8 +503,14 @@ int d3d_roi_align_rotated_3d_sparse_backward(d3d_meta *m, const int *size, const
                                              void *stream) {
   hipStream_t s = (hipStream_t)stream;
   D3D_REQUIRE(m && size && crop && C > 0 && K >= 0 && ph > 0 && pw > 0 && pz > 0, "roi_align_sparse_backward: bad arguments");
-  auto it = m->grids.find(Size3{size[0], size[1], size[2]});
-  if (it == m->grids.end()) {
+  std::map<Size3, Grid>::iterator it;
+  bool have_grid;
+  {
+    D3D_LOCK(m);
+    it = m->grids.find(Size3{size[0], size[1], size[2]});
+    have_grid = it != m->grids.end();
+  }
+  if (!have_grid) {
     set_error("roi_align_sparse_backward: no grid of spatial size [%d,%d,%d]", size[0], size[1], size[2]);
     return D3D_ERR_STATE;
   }

@@ -210,6 +210,22 @@ class Metadata_3(object):
         on; None lifts the restriction."""
         check(lib().d3d_meta_set_geometry_stream(self._h, ctypes.c_void_p(raw_stream or 0), int(raw_stream is not None)))
 
+    def geometry_async_start(self, specs, raw_stream):
+        """d3d_geometry_async_start: `specs` rows of 12 ints (in_size, out_size, filter, stride), built in order by a
+        thread of the library on the geometry stream `raw_stream`."""
+        flat = [int(v) for row in specs for v in row]
+        arr = (ctypes.c_int * max(1, len(flat)))(*flat)
+        check(lib().d3d_geometry_async_start(self._h, arr, len(specs), ctypes.c_void_p(raw_stream)))
+
+    def geometry_async_wait(self, index, raw_wait_stream):
+        """-> output site count of entry `index` once it is built; `raw_wait_stream` is made to wait for it"""
+        n = ctypes.c_int(0)
+        check(lib().d3d_geometry_async_wait(self._h, int(index), ctypes.byref(n), ctypes.c_void_p(raw_wait_stream)))
+        return n.value
+
+    def geometry_async_finish(self):
+        check(lib().d3d_geometry_async_finish(self._h))
+
     def set_plan_stream(self, raw_stream):
         """d3d_meta_set_plan_stream: submanifold / deconvolution rulebooks built on `raw_stream` get a lane of the arena
         of their own (a geometry stream must be set); None ends the routing."""

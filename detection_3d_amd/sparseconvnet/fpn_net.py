@@ -21,6 +21,8 @@ from ..timeline import mark as _tmark
 TWO_LANE = True     # grid chain of the coarser levels on a side stream while the finer ones convolve
 PLAN_LANE = os.environ.get("D3D_PLAN_LANE", "0") != "0"   # ... and each level's submanifold / deconvolution rulebooks on a third
                     # (measured: 6.2-6.6 ms per building against 6.1-6.4 without -- the kernels it overlaps slow each other down)
+ASYNC_GEOMETRY = os.environ.get("D3D_ASYNC_GEOMETRY", "1") != "0"   # the grid chain is run by a thread of the library
+                    # (d3d_geometry_async_*): its count read-backs no longer stop this thread from enqueueing
 _GEO_STREAMS = {}   # (device, caller's stream) -> high-priority side streams
 
 
@@ -131,9 +133,95 @@ class FPN_Net(torch.nn.Module):
 
     def forward(self, net0):
         if TWO_LANE and _is_gpu_input(net0):
+            if ASYNC_GEOMETRY and not PLAN_LANE:
+                return self._forward_async_geometry(net0)
             return self._forward_two_lane(net0)
         net1 = self.layers_in[1](self._to_compute(self.layers_in[0](net0)))
         return self.forward_fpn(net1)
+
+    def _geometry_specs(self, size0):
+        """The d3d_conv_prepare calls of the pyramid in the order _geometry_steps makes them, as rows of 12 ints
+        (in_size, out_size, filter, stride), and for every level the index of its last row (-1: none)."""
+        n_scales = len(self.m_downs)
+        n3d = len(self.fpn_scales_from_top)
+        sel2d = sorted({i - n3d for i in self.rpn_3d_2d_selector if i >= n3d}) if self.skip_unused else range(n3d)
+        pro2d = {n_scales - 1 - self.fpn_scales_from_top[i]: self.convs_pro2d[i] for i in sel2d}
+        size = scn.toLongTensor(self.dimension, size0)
+        specs, last = [], []
+        for k in range(n_scales):
+            if k > 0:
+                filt = scn.toLongTensor(self.dimension, self.down_kernels[k - 1])
+                stride = scn.toLongTensor(self.dimension, self.down_strides[k - 1])
+                out = (size - filt) // stride + 1
+                specs.append(size.tolist() + out.tolist() + filt.tolist() + stride.tolist())
+                size = out
+            if k in pro2d:
+                conv = pro2d[k]
+                out = (size - conv.filter_size) // conv.filter_stride + 1
+                specs.append(size.tolist() + out.tolist() + conv.filter_size.tolist() + conv.filter_stride.tolist())
+            last.append(len(specs) - 1 if (k > 0 or k in pro2d) else -1)
+        return specs, last
+
+    def _forward_async_geometry(self, net0):
+        """The two-stream pass with the grid chain run by a thread of the library (d3d_geometry_async_start): every new
+        grid costs a blocking read-back of its site count, and while this thread waited for one it could not enqueue
+        the feature kernels of the level before -- by the end of the bottom-up path the caller's stream had caught up
+        with its own launch thread.  Here the chain of all levels starts right after the input grid exists and runs at
+        its own pace on the geometry stream; this thread picks a level's grid up (count + stream dependency) when it
+        is about to enqueue that level.  Same kernels on the same data (bit-identical)."""
+        main = torch.cuda.current_stream(net0[1].device)
+        geo, pool = _geometry_stream(main)[:2]
+        plan0 = pool[-1]
+        state = {}
+
+        def after_input_build(md, size):
+            geo.wait_stream(main)
+            md.set_geometry_stream(geo.cuda_stream)
+            scn.SCN.SubmanifoldConvolution_prepare(size, (3,) * self.dimension, md)     # level 0, on this stream
+            with torch.cuda.stream(geo):
+                scn.SCN.InputLayer_prepare(md)              # point lists (geometry lane of the arena) first ...
+                plan0.record(geo)
+            cache = getattr(self, "_spec_cache", None)
+            key = tuple(scn.SCN._size3(size))
+            if cache is None or cache[0] != key:
+                cache = self._spec_cache = (key,) + self._geometry_specs(size)
+            state["last"] = cache[2]
+            md.geometry_async_start(cache[1], geo.cuda_stream)      # ... then the lane belongs to the chain's thread
+            state["md"] = md
+            main.wait_event(plan0)
+
+        scn.SCN.set_after_input_build(after_input_build)
+        try:
+            net = self.layers_in[0](net0)                   # input layer: grid of level 0
+        finally:
+            scn.SCN.set_after_input_build(None)
+        md = net.metadata
+        n_scales = len(self.m_downs)
+        try:
+            if "md" not in state:                           # (an input layer that did not go through the hook)
+                after_input_build(md, net.spatial_size)
+
+            def lane(k):
+                if k >= n_scales:
+                    return
+                _tmark("host enters", k, host=True)
+                _tmark("main arrives", k, main)
+                idx = state["last"][k]
+                if idx >= 0:
+                    md.geometry_async_wait(idx, main.cuda_stream)
+                _tmark("main continues", k, main)
+                _tmark("host leaves", k, host=True)
+
+            lane(0)
+            net = self.layers_in[1](self._to_compute(net))
+            out = self.forward_fpn(net, prepared=True, lane=lane)
+        finally:
+            try:
+                md.geometry_async_finish()
+            finally:
+                main.wait_stream(geo)
+                md.set_geometry_stream(None)
+        return out
 
     def _forward_two_lane(self, net0):
         """Forward pass on three HIP streams: the chain of strided grids (small dependent kernels and one count

@@ -1,5 +1,6 @@
 """Host-side helpers of the operator mirror (CPU): cached size tuples / ctypes arrays, the no-grad bypass of
 autograd.Function.apply, the geometry schedule of FPN_Net (which level builds which grid / rulebook)."""
+import pytest
 import torch
 
 from detection_3d_amd import _lib
@@ -80,3 +81,28 @@ def test_geometry_schedule_of_the_4c_backbone(monkeypatch):
     calls.clear()
     net.prepare_geometry(Net0(), full=False)
     assert calls and all(c[0] == "grid" for c in calls)
+
+
+@pytest.mark.parametrize("name", ["4c_Fpn432", "3G6c_Fpn4321"])
+def test_async_geometry_specs_are_the_grid_calls_of_the_schedule(monkeypatch, name):
+    """FPN_Net._geometry_specs -- the list the library's geometry thread works through (d3d_geometry_async_start) -- holds
+    exactly the d3d_conv_prepare calls _geometry_steps makes, in the same order, and `last[k]` points at the last one a
+    level needs before its convolutions may be enqueued."""
+    cfg = get_cfg(name)
+    net = build_backbone(cfg)
+    calls = []
+    monkeypatch.setattr(SCN, "Convolution_prepare",
+                        lambda i, o, f, s, m: calls.append(SCN._size3(i) + SCN._size3(o) + SCN._size3(f) + SCN._size3(s)) or 1)
+
+    class Net0(object):
+        spatial_size = torch.LongTensor(cfg.SPARSE3D.VOXEL_FULL_SCALE)
+        metadata = None
+
+    per_level = []
+    for k in net._geometry_steps(Net0(), False):
+        per_level.append(len(calls))
+    specs, last = net._geometry_specs(Net0.spatial_size)
+    assert [tuple(s) for s in specs] == calls and len(last) == len(net.m_downs)
+    for k, n_after in enumerate(per_level):
+        before = per_level[k - 1] if k else 0
+        assert last[k] == (n_after - 1 if n_after > before else -1)

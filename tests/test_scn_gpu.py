@@ -395,3 +395,59 @@ def test_backbone_with_and_without_epilogue_statistics(dev):
     for a, b, c in zip(*outs):
         assert torch.equal(a, b)
         assert rel_err(a.cpu().numpy(), c.cpu().numpy()) < 1e-5
+
+
+def test_geometry_chain_on_the_library_thread_equals_the_calls_made_in_line(dev):
+    """d3d_geometry_async_start / _wait / _finish: the chain of strided grids built by the library's own thread gives the
+    grids (site counts, coordinates in the same numbering) and rulebooks of the same d3d_conv_prepare calls made one
+    after the other by the caller; an impossible entry is reported by wait / finish instead of hanging."""
+    from detection_3d_amd import sparseconvnet as scn
+    from detection_3d_amd._lib import D3DError
+    size = (256, 256, 32)
+    _, coords, feats = small_scene(21, 60000, (5.0, 4.0, 0.6), size)
+    inp = [torch.from_numpy(coords), torch.from_numpy(feats).to(dev)]
+    specs, cur = [], list(size)
+    for _ in range(4):
+        nxt = [v // 2 for v in cur]
+        specs.append(cur + nxt + [2, 2, 2] + [2, 2, 2])
+        cur = nxt
+    specs.append(cur + [cur[0], cur[1], 1] + [1, 1, cur[2]] + [1, 1, 1])           # a z-collapsing projection grid
+    with torch.no_grad():
+        a = scn.InputLayer(3, size, mode=4)(inp)
+        b = scn.InputLayer(3, size, mode=4)(inp)
+    want = [scn.SCN.Convolution_prepare(sp[0:3], sp[3:6], sp[6:9], sp[9:12], a.metadata) for sp in specs]
+    main = torch.cuda.current_stream(dev)
+    geo = torch.cuda.Stream(device=dev)
+    md = b.metadata
+    geo.wait_stream(main)
+    md.set_geometry_stream(geo.cuda_stream)
+    try:
+        md.geometry_async_start(specs, geo.cuda_stream)
+        got = [md.geometry_async_wait(i, main.cuda_stream) for i in (2, 0, 4, 1, 3)]     # any order, any number of times
+        md.geometry_async_finish()
+    finally:
+        main.wait_stream(geo)
+        md.set_geometry_stream(None)
+    assert got == [want[i] for i in (2, 0, 4, 1, 3)] and min(want) > 0
+    for sp in specs:
+        la, lb = a.metadata.getSpatialLocations(sp[3:6]), md.getSpatialLocations(sp[3:6])
+        assert torch.equal(la, lb)
+        ra = a.metadata.export_rules(1, sp[0:3], sp[6:9], sp[9:12])
+        rb = md.export_rules(1, sp[0:3], sp[6:9], sp[9:12])
+        assert np.array_equal(canon_rules(ra.cpu().numpy()), canon_rules(rb.cpu().numpy()))
+    # an entry that cannot be built (its input grid does not exist): error on wait and on finish, no hang
+    with torch.no_grad():
+        c = scn.InputLayer(3, size, mode=4)(inp)
+    md = c.metadata
+    geo.wait_stream(main)
+    md.set_geometry_stream(geo.cuda_stream)
+    try:
+        md.geometry_async_start([specs[0], [64, 64, 8, 32, 32, 4, 2, 2, 2, 2, 2, 2]], geo.cuda_stream)
+        assert md.geometry_async_wait(0, main.cuda_stream) == want[0]
+        with pytest.raises(D3DError, match="geometry thread"):
+            md.geometry_async_wait(1, main.cuda_stream)
+        with pytest.raises(D3DError, match="geometry thread"):
+            md.geometry_async_finish()
+    finally:
+        main.wait_stream(geo)
+        md.set_geometry_stream(None)
