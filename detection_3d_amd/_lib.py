@@ -32,7 +32,7 @@ _SIGS = {
     "d3d_meta_arena_used": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_size_t)]),
     "d3d_meta_set_geometry_stream": (ctypes.c_int, [vp, vp, ctypes.c_int]),
     "d3d_meta_set_plan_stream": (ctypes.c_int, [vp, vp, ctypes.c_int]),
-    "d3d_geometry_async_start": (ctypes.c_int, [vp, vp, ctypes.c_int, vp]),
+    "d3d_geometry_async_start": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, vp]),
     "d3d_geometry_async_wait": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int), vp]),
     "d3d_geometry_async_finish": (ctypes.c_int, [vp]),
     "d3d_sort_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),

@@ -1040,21 +1040,23 @@ namespace d3d {
 // while it waits.  The thread builds the listed rulebooks in order on the geometry stream and publishes, per entry,
 // the output site count and an event; the caller picks an entry up when it needs it (d3d_geometry_async_wait).
 struct GeoAsync {
-  std::thread th;
+  std::thread th, th_views;                 // the grids (blocking read-backs) / the views behind them
   std::mutex mu;
   std::condition_variable cv;
-  std::vector<std::array<int, 12>> specs;   // in_size, out_size, filter, stride
+  std::vector<std::array<int, 13>> specs;   // kind, in_size, out_size, filter, stride
   std::vector<int> n_out;
   std::vector<hipEvent_t> ev;               // pool, reused from scene to scene
-  int done = 0, rc = 0, device = 0;
+  std::vector<char> ready;                  // entry built (grids) / enqueued (views)
+  int rc = 0, device = 0;
   bool running = false;
   std::string err;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, view_stream = nullptr;
 };
 static void geo_async_join(d3d_meta *m) {
   GeoAsync *g = (GeoAsync *)m->geo_async;
   if (g && g->running) {
     if (g->th.joinable()) g->th.join();
+    if (g->th_views.joinable()) g->th_views.join();
     g->running = false;
   }
 }
@@ -1584,52 +1586,104 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
   return D3D_OK;
 }
 
-int d3d_geometry_async_start(d3d_meta *m, const int *specs, int n, void *stream) {
-  D3D_REQUIRE(m && (n == 0 || specs) && n >= 0 && n <= 64, "geometry_async_start: bad arguments");
+int d3d_geometry_async_start(d3d_meta *m, const int *specs, int n, void *stream, void *view_stream) {
+  D3D_REQUIRE(m && (n == 0 || specs) && n >= 0 && n <= 128, "geometry_async_start: bad arguments");
   D3D_REQUIRE(m->geo_locked && (hipStream_t)stream == m->geo_stream,
               "geometry_async_start: `stream` must be the metadata's geometry stream (d3d_meta_set_geometry_stream)");
+  for (int i = 0; i < n; i++) {
+    const int kind = specs[i * 13];
+    D3D_REQUIRE(kind >= 0 && kind <= 2, "geometry_async_start: entry %d has kind %d (0 submanifold view, 1 strided grid, "
+                "2 deconvolution view)", i, kind);
+    D3D_REQUIRE(kind == 1 || (view_stream && (hipStream_t)view_stream == m->plan_stream),
+                "geometry_async_start: views need the metadata's plan stream (d3d_meta_set_plan_stream)");
+  }
   geo_async_join(m);
   GeoAsync *g = (GeoAsync *)m->geo_async;
   if (!g) m->geo_async = g = new GeoAsync();
   g->specs.resize(n);
   for (int i = 0; i < n; i++)
-    for (int j = 0; j < 12; j++) g->specs[i][j] = specs[i * 12 + j];
+    for (int j = 0; j < 13; j++) g->specs[i][j] = specs[i * 13 + j];
   g->n_out.assign(n, 0);
   while ((int)g->ev.size() < n) {
     hipEvent_t e;
     D3D_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     g->ev.push_back(e);
   }
-  g->done = 0;
+  g->ready.assign(n, 0);
   g->rc = D3D_OK;
   g->err.clear();
   g->stream = (hipStream_t)stream;
+  g->view_stream = (hipStream_t)view_stream;
   D3D_HIP_CHECK(hipGetDevice(&g->device));
   if (n == 0) return D3D_OK;
   g->running = true;
-  g->th = std::thread([m, g]() {
-    int rc = hipSetDevice(g->device) == hipSuccess ? D3D_OK : D3D_ERR_HIP;
-    if (rc) set_error("geometry thread: hipSetDevice(%d) failed", g->device);
+  // publishes the outcome of entry i; returns false when the chain has failed (here or in the other thread)
+  auto publish = [g](int i, int rc, int n_out) {
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (rc == D3D_OK) {
+      g->n_out[i] = n_out;
+      g->ready[i] = 1;
+    } else if (g->rc == D3D_OK) {
+      g->rc = rc;
+      g->err = d3d_last_error();
+    }
+    g->cv.notify_all();
+    return g->rc == D3D_OK;
+  };
+  auto begin = [g]() {
+    if (hipSetDevice(g->device) == hipSuccess) return (int)D3D_OK;
+    set_error("geometry thread: hipSetDevice(%d) failed", g->device);
+    return (int)D3D_ERR_HIP;
+  };
+  g->th = std::thread([m, g, publish, begin]() {     // the grids, in order; each one blocks on its count read-back
+    int rc = begin();
     const int n = (int)g->specs.size();
-    for (int i = 0; i < n && rc == D3D_OK; i++) {
-      const int *sp = g->specs[i].data();
+    for (int i = 0; i < n; i++) {
+      if (g->specs[i][0] != 1) continue;
+      const int *sp = g->specs[i].data() + 1;
       int n_out = 0;
-      rc = d3d_conv_prepare(m, sp, sp + 3, sp + 6, sp + 9, g->stream, &n_out, nullptr);
+      if (rc == D3D_OK) rc = d3d_conv_prepare(m, sp, sp + 3, sp + 6, sp + 9, g->stream, &n_out, nullptr);
       if (rc == D3D_OK && hipEventRecord(g->ev[i], g->stream) != hipSuccess) {
         set_error("geometry thread: hipEventRecord failed");
         rc = D3D_ERR_HIP;
       }
-      std::lock_guard<std::mutex> lk(g->mu);
-      if (rc == D3D_OK) {
-        g->n_out[i] = n_out;
-        g->done = i + 1;
-      } else {
-        g->rc = rc;
-        g->err = d3d_last_error();
-      }
-      g->cv.notify_all();
+      if (!publish(i, rc, n_out)) return;
     }
   });
+  bool any_view = false;
+  for (int i = 0; i < n; i++) any_view = any_view || g->specs[i][0] != 1;
+  if (any_view)
+    g->th_views = std::thread([m, g, publish, begin]() {   // the views: each behind the newest grid listed before it
+      int rc = begin();
+      const int n = (int)g->specs.size();
+      int dep = -1;
+      for (int i = 0; i < n; i++) {
+        const int kind = g->specs[i][0];
+        if (kind == 1) {
+          dep = i;
+          continue;
+        }
+        if (dep >= 0) {
+          std::unique_lock<std::mutex> lk(g->mu);
+          g->cv.wait(lk, [&] { return g->ready[dep] || g->rc != D3D_OK; });
+          if (!g->ready[dep]) return;
+        }
+        const int *sp = g->specs[i].data() + 1;
+        hipStream_t on = g->view_stream;
+        if (rc == D3D_OK && dep >= 0 && hipStreamWaitEvent(on, g->ev[dep], 0) != hipSuccess) {
+          set_error("geometry thread: hipStreamWaitEvent failed");
+          rc = D3D_ERR_HIP;
+        }
+        if (rc == D3D_OK)
+          rc = kind == 0 ? d3d_subm_prepare(m, sp, sp + 6, on, nullptr)
+                         : d3d_deconv_prepare(m, sp, sp + 3, sp + 6, sp + 9, on, nullptr);
+        if (rc == D3D_OK && hipEventRecord(g->ev[i], on) != hipSuccess) {
+          set_error("geometry thread: hipEventRecord failed");
+          rc = D3D_ERR_HIP;
+        }
+        if (!publish(i, rc, 0)) return;
+      }
+    });
   return D3D_OK;
 }
 
@@ -1639,14 +1693,14 @@ int d3d_geometry_async_wait(d3d_meta *m, int index, int *n_out_host, void *wait_
   D3D_REQUIRE(index >= 0 && index < (int)g->specs.size(), "geometry_async_wait: entry %d of %d", index, (int)g->specs.size());
   {
     std::unique_lock<std::mutex> lk(g->mu);
-    g->cv.wait(lk, [&] { return g->done > index || g->rc != D3D_OK; });
-    if (g->done <= index) {
+    g->cv.wait(lk, [&] { return g->ready[index] || g->rc != D3D_OK; });
+    if (!g->ready[index]) {
       set_error("geometry thread: %s", g->err.c_str());
       return g->rc;
     }
     if (n_out_host) *n_out_host = g->n_out[index];
   }
-  if (wait_stream != (void *)g->stream) D3D_HIP_CHECK(hipStreamWaitEvent((hipStream_t)wait_stream, g->ev[index], 0));
+  D3D_HIP_CHECK(hipStreamWaitEvent((hipStream_t)wait_stream, g->ev[index], 0));
   return D3D_OK;
 }
 

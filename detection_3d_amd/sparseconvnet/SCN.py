@@ -210,12 +210,15 @@ class Metadata_3(object):
         on; None lifts the restriction."""
         check(lib().d3d_meta_set_geometry_stream(self._h, ctypes.c_void_p(raw_stream or 0), int(raw_stream is not None)))
 
-    def geometry_async_start(self, specs, raw_stream):
-        """d3d_geometry_async_start: `specs` rows of 12 ints (in_size, out_size, filter, stride), built in order by a
-        thread of the library on the geometry stream `raw_stream`."""
+    def geometry_async_start(self, specs, raw_stream, raw_view_stream=None):
+        """d3d_geometry_async_start: `specs` rows of 13 ints (kind, in_size, out_size, filter, stride; kind 1 = strided grid
+        on the geometry stream `raw_stream`, 0 / 2 = submanifold / deconvolution view on the plan stream
+        `raw_view_stream`), built in order by a thread of the library."""
         flat = [int(v) for row in specs for v in row]
+        assert len(flat) == 13 * len(specs)
         arr = (ctypes.c_int * max(1, len(flat)))(*flat)
-        check(lib().d3d_geometry_async_start(self._h, arr, len(specs), ctypes.c_void_p(raw_stream)))
+        check(lib().d3d_geometry_async_start(self._h, arr, len(specs), ctypes.c_void_p(raw_stream),
+                                             ctypes.c_void_p(raw_view_stream or 0)))
 
     def geometry_async_wait(self, index, raw_wait_stream):
         """-> output site count of entry `index` once it is built; `raw_wait_stream` is made to wait for it"""

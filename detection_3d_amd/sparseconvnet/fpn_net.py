@@ -23,6 +23,7 @@ PLAN_LANE = os.environ.get("D3D_PLAN_LANE", "0") != "0"   # ... and each level's
                     # (measured: 6.2-6.6 ms per building against 6.1-6.4 without -- the kernels it overlaps slow each other down)
 ASYNC_GEOMETRY = os.environ.get("D3D_ASYNC_GEOMETRY", "1") != "0"   # the grid chain is run by a thread of the library
                     # (d3d_geometry_async_*): its count read-backs no longer stop this thread from enqueueing
+ASYNC_VIEWS = os.environ.get("D3D_ASYNC_VIEWS", "1") != "0"         # ... and that thread also enqueues the views (third stream)
 _GEO_STREAMS = {}   # (device, caller's stream) -> high-priority side streams
 
 
@@ -139,54 +140,82 @@ class FPN_Net(torch.nn.Module):
         net1 = self.layers_in[1](self._to_compute(self.layers_in[0](net0)))
         return self.forward_fpn(net1)
 
-    def _geometry_specs(self, size0):
-        """The d3d_conv_prepare calls of the pyramid in the order _geometry_steps makes them, as rows of 12 ints
-        (in_size, out_size, filter, stride), and for every level the index of its last row (-1: none)."""
+    def _geometry_specs(self, size0, views=False):
+        """The d3d_conv_prepare calls of the pyramid in the order _geometry_steps makes them, as rows of 13 ints
+        (kind 1, in_size, out_size, filter, stride), and for every level the index of the last row it needs before its
+        convolutions may be enqueued (-1: none).  With `views` the rulebooks that are views of a grid are listed too
+        (what _geometry_steps builds with full=True): the 3x3x3 submanifold rulebook (kind 0) of every level but the
+        first right behind its grid -- the row a level then waits for -- and, after all grids, the lateral 1x1x1
+        rulebooks and the deconvolution views (kind 2) of the top-down path.
+        -> (rows, last row per level, last row of all)"""
         n_scales = len(self.m_downs)
         n3d = len(self.fpn_scales_from_top)
         sel2d = sorted({i - n3d for i in self.rpn_3d_2d_selector if i >= n3d}) if self.skip_unused else range(n3d)
         pro2d = {n_scales - 1 - self.fpn_scales_from_top[i]: self.convs_pro2d[i] for i in sel2d}
+        needed = max(self.fpn_scales_from_top + self.roi_scales_from_top) if self.skip_unused else n_scales - 1
+        lowest_up = n_scales - 1 - min(n_scales - 1, needed)
         size = scn.toLongTensor(self.dimension, size0)
-        specs, last = [], []
+        three, one = [3] * self.dimension, [1] * self.dimension
+        specs, last, later, sizes = [], [], [], []
         for k in range(n_scales):
             if k > 0:
                 filt = scn.toLongTensor(self.dimension, self.down_kernels[k - 1])
                 stride = scn.toLongTensor(self.dimension, self.down_strides[k - 1])
                 out = (size - filt) // stride + 1
-                specs.append(size.tolist() + out.tolist() + filt.tolist() + stride.tolist())
+                specs.append([1] + size.tolist() + out.tolist() + filt.tolist() + stride.tolist())
+                if views and k > lowest_up:
+                    later.append([2] + out.tolist() + size.tolist() + filt.tolist() + stride.tolist())
                 size = out
+            sizes.append(size)
             if k in pro2d:
                 conv = pro2d[k]
                 out = (size - conv.filter_size) // conv.filter_stride + 1
-                specs.append(size.tolist() + out.tolist() + conv.filter_size.tolist() + conv.filter_stride.tolist())
+                specs.append([1] + size.tolist() + out.tolist() + conv.filter_size.tolist() + conv.filter_stride.tolist())
+            if views:
+                if k > 0:           # (level 0's is built by the caller while the point lists are sorted)
+                    specs.append([0] + size.tolist() + size.tolist() + three + one)
+                if k >= lowest_up:
+                    later.append([0] + size.tolist() + size.tolist() + one + one)
             last.append(len(specs) - 1 if (k > 0 or k in pro2d) else -1)
-        return specs, last
+        specs += later
+        return specs, last, len(specs) - 1
 
     def _forward_async_geometry(self, net0):
-        """The two-stream pass with the grid chain run by a thread of the library (d3d_geometry_async_start): every new
-        grid costs a blocking read-back of its site count, and while this thread waited for one it could not enqueue
-        the feature kernels of the level before -- by the end of the bottom-up path the caller's stream had caught up
-        with its own launch thread.  Here the chain of all levels starts right after the input grid exists and runs at
-        its own pace on the geometry stream; this thread picks a level's grid up (count + stream dependency) when it
-        is about to enqueue that level.  Same kernels on the same data (bit-identical)."""
+        """The pass with the grid chain run by a thread of the library (d3d_geometry_async_start): every new grid costs
+        a blocking read-back of its site count, and while this thread waited for one it could not enqueue the feature
+        kernels of the level before -- by the end of the bottom-up path the caller's stream had caught up with its own
+        launch thread.  Here the chain of all levels starts right after the input grid exists and runs at its own pace
+        on the geometry stream; this thread picks a level up (count + stream dependency) when it is about to enqueue
+        it.  With ASYNC_VIEWS the same thread also enqueues, on a third stream, the rulebooks that are views of a
+        finished grid (3x3x3 right behind each grid; lateral and deconvolution views at the end).  Same kernels on the
+        same data (bit-identical)."""
         main = torch.cuda.current_stream(net0[1].device)
-        geo, pool = _geometry_stream(main)[:2]
+        geo, pool, plan = _geometry_stream(main)[:3]
+        if not ASYNC_VIEWS:
+            plan = None
         plan0 = pool[-1]
         state = {}
 
         def after_input_build(md, size):
             geo.wait_stream(main)
             md.set_geometry_stream(geo.cuda_stream)
-            scn.SCN.SubmanifoldConvolution_prepare(size, (3,) * self.dimension, md)     # level 0, on this stream
+            # level 0's 3x3x3 rulebook on this stream (hash probes + sort, ~0.3 ms) while the geometry stream sorts the
+            # point lists; the plan lane is carved out of the feature lane only afterwards, and its stream starts behind
+            # this build (whose scratch may reach into what becomes the plan lane)
+            scn.SCN.SubmanifoldConvolution_prepare(size, (3,) * self.dimension, md)
+            if plan is not None:
+                plan.wait_stream(main)
+                md.set_plan_stream(plan.cuda_stream)
             with torch.cuda.stream(geo):
                 scn.SCN.InputLayer_prepare(md)              # point lists (geometry lane of the arena) first ...
                 plan0.record(geo)
             cache = getattr(self, "_spec_cache", None)
-            key = tuple(scn.SCN._size3(size))
+            key = tuple(scn.SCN._size3(size)) + (plan is not None,)
             if cache is None or cache[0] != key:
-                cache = self._spec_cache = (key,) + self._geometry_specs(size)
-            state["last"] = cache[2]
-            md.geometry_async_start(cache[1], geo.cuda_stream)      # ... then the lane belongs to the chain's thread
+                cache = self._spec_cache = (key,) + self._geometry_specs(size, views=plan is not None)
+            state["last"], state["all"] = cache[2], cache[3]
+            # ... then both lanes belong to the chain's thread
+            md.geometry_async_start(cache[1], geo.cuda_stream, plan.cuda_stream if plan is not None else None)
             state["md"] = md
             main.wait_event(plan0)
 
@@ -202,12 +231,10 @@ class FPN_Net(torch.nn.Module):
                 after_input_build(md, net.spatial_size)
 
             def lane(k):
-                if k >= n_scales:
-                    return
                 _tmark("host enters", k, host=True)
                 _tmark("main arrives", k, main)
-                idx = state["last"][k]
-                if idx >= 0:
+                idx = state["all"] if k >= n_scales else state["last"][k]
+                if idx >= 0 and (k < n_scales or plan is not None):
                     md.geometry_async_wait(idx, main.cuda_stream)
                 _tmark("main continues", k, main)
                 _tmark("host leaves", k, host=True)
@@ -220,6 +247,9 @@ class FPN_Net(torch.nn.Module):
                 md.geometry_async_finish()
             finally:
                 main.wait_stream(geo)
+                if plan is not None:
+                    main.wait_stream(plan)
+                    md.set_plan_stream(None)
                 md.set_geometry_stream(None)
         return out
 

@@ -56,12 +56,16 @@ int d3d_meta_arena_used(d3d_meta *m, size_t *bytes_host);
 int d3d_meta_set_geometry_stream(d3d_meta *m, void *stream, int enable);
 /* The chain of strided grids run by a thread of the library (no reference counterpart; every new grid costs one blocking
  * read-back of its site count, during which a caller that builds the chain itself cannot enqueue feature kernels).
- * start: `specs` = n x 12 ints (in_size[3], out_size[3], filter[3], stride[3]), the d3d_conv_prepare calls to make, in
- * order, on `stream` -- which must be the metadata's geometry stream; the caller has already ordered that stream after
- * whatever built the first input grid and must not build on it (or touch the geometry lane of the arena) until finish.
- * wait: blocks until entry `index` is built, returns its output site count and makes `wait_stream` wait for it.
+ * start: `specs` = n x 13 ints (kind, in_size[3], out_size[3], filter[3], stride[3]), built in order:
+ *   kind 1: d3d_conv_prepare (a new grid + strided rulebook) on `stream`, which must be the metadata's geometry stream;
+ *   kind 0: d3d_subm_prepare(in_size, filter), kind 2: d3d_deconv_prepare -- views of grids that exist by then, enqueued
+ *           on `view_stream` (the metadata's plan stream, d3d_meta_set_plan_stream) behind the newest grid.
+ * The caller has already ordered `stream` after whatever built the first input grid and must not build on either stream
+ * (or touch their lanes of the arena) until finish.
+ * wait: blocks until entry `index` is built (enqueued, for views), returns its output site count (kind 1) and makes
+ *       `wait_stream` wait for it.
  * finish: joins the thread (d3d_meta_clear / _destroy do so too) and reports its error, if any.                       */
-int d3d_geometry_async_start(d3d_meta *m, const int *specs_host, int n, void *stream);
+int d3d_geometry_async_start(d3d_meta *m, const int *specs_host, int n, void *stream, void *view_stream);
 int d3d_geometry_async_wait(d3d_meta *m, int index, int *n_out_host, void *wait_stream);
 int d3d_geometry_async_finish(d3d_meta *m);
 /* Third lane (needs a geometry stream): rulebooks that are views of an existing grid -- submanifold, deconvolution --

@@ -101,8 +101,26 @@ def test_async_geometry_specs_are_the_grid_calls_of_the_schedule(monkeypatch, na
     per_level = []
     for k in net._geometry_steps(Net0(), False):
         per_level.append(len(calls))
-    specs, last = net._geometry_specs(Net0.spatial_size)
-    assert [tuple(s) for s in specs] == calls and len(last) == len(net.m_downs)
+    specs, last, last_all = net._geometry_specs(Net0.spatial_size)
+    assert all(s[0] == 1 for s in specs) and [tuple(s[1:]) for s in specs] == calls
+    assert len(last) == len(net.m_downs) and last_all == len(specs) - 1
     for k, n_after in enumerate(per_level):
         before = per_level[k - 1] if k else 0
         assert last[k] == (n_after - 1 if n_after > before else -1)
+    # with the views: the same grids in the same order, every level waits for its 3x3x3 rulebook (listed right behind
+    # its grids), and the rulebooks of the top-down path -- the `full` ones of _geometry_steps -- come last
+    v, vlast, vall = net._geometry_specs(Net0.spatial_size, views=True)
+    assert [tuple(s[1:]) for s in v if s[0] == 1] == calls and vall == len(v) - 1
+    full = []
+    monkeypatch.setattr(SCN, "SubmanifoldConvolution_prepare", lambda sz, f, m: full.append((0, SCN._size3(sz), SCN._size3(f))))
+    monkeypatch.setattr(SCN, "Deconvolution_prepare", lambda i, o, f, s, m: full.append((2, SCN._size3(i), SCN._size3(o))))
+    for k in net._geometry_steps(Net0(), True):
+        pass
+    got = [(s[0], tuple(s[1:4]), tuple(s[7:10])) if s[0] == 0 else (2, tuple(s[1:4]), tuple(s[4:7])) for s in v if s[0] != 1]
+    size0 = tuple(cfg.SPARSE3D.VOXEL_FULL_SCALE)
+    assert sorted(got + [(0, size0, (3, 3, 3))]) == sorted(full)      # (level 0's 3x3x3 is the caller's)
+    for k, idx in enumerate(vlast):
+        if k == 0:
+            continue
+        assert v[idx][0] == 0 and tuple(v[idx][7:10]) == (3, 3, 3)
+        assert all(s[0] == 1 or tuple(s[7:10]) == (3, 3, 3) for s in v[:idx + 1])

@@ -409,31 +409,50 @@ def test_geometry_chain_on_the_library_thread_equals_the_calls_made_in_line(dev)
     specs, cur = [], list(size)
     for _ in range(4):
         nxt = [v // 2 for v in cur]
-        specs.append(cur + nxt + [2, 2, 2] + [2, 2, 2])
+        specs.append([1] + cur + nxt + [2, 2, 2] + [2, 2, 2])
         cur = nxt
-    specs.append(cur + [cur[0], cur[1], 1] + [1, 1, cur[2]] + [1, 1, 1])           # a z-collapsing projection grid
+    specs.append([1] + cur + [cur[0], cur[1], 1] + [1, 1, cur[2]] + [1, 1, 1])     # a z-collapsing projection grid
     with torch.no_grad():
         a = scn.InputLayer(3, size, mode=4)(inp)
         b = scn.InputLayer(3, size, mode=4)(inp)
-    want = [scn.SCN.Convolution_prepare(sp[0:3], sp[3:6], sp[6:9], sp[9:12], a.metadata) for sp in specs]
+    want = [scn.SCN.Convolution_prepare(sp[1:4], sp[4:7], sp[7:10], sp[10:13], a.metadata) for sp in specs]
+    # views of the grids, listed behind them: 3x3x3 submanifold rulebooks (kind 0) and deconvolution views (kind 2)
+    views = [[0] + sp[1:4] + sp[1:4] + [3, 3, 3] + [1, 1, 1] for sp in specs[:4]]
+    views += [[2] + sp[4:7] + sp[1:4] + sp[7:10] + sp[10:13] for sp in specs[:4]]
+    for v in views:
+        if v[0] == 0:
+            scn.SCN.SubmanifoldConvolution_prepare(v[1:4], v[7:10], a.metadata)
+        else:
+            scn.SCN.Deconvolution_prepare(v[1:4], v[4:7], v[7:10], v[10:13], a.metadata)
     main = torch.cuda.current_stream(dev)
-    geo = torch.cuda.Stream(device=dev)
+    geo, plan = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
     md = b.metadata
     geo.wait_stream(main)
+    plan.wait_stream(main)
     md.set_geometry_stream(geo.cuda_stream)
+    md.set_plan_stream(plan.cuda_stream)
     try:
-        md.geometry_async_start(specs, geo.cuda_stream)
+        with pytest.raises(Exception, match="plan stream"):
+            md.geometry_async_start(specs + views, geo.cuda_stream)                     # views need their stream
+        md.geometry_async_start(specs + views, geo.cuda_stream, plan.cuda_stream)
         got = [md.geometry_async_wait(i, main.cuda_stream) for i in (2, 0, 4, 1, 3)]     # any order, any number of times
+        md.geometry_async_wait(len(specs) + len(views) - 1, main.cuda_stream)
         md.geometry_async_finish()
     finally:
         main.wait_stream(geo)
+        main.wait_stream(plan)
+        md.set_plan_stream(None)
         md.set_geometry_stream(None)
     assert got == [want[i] for i in (2, 0, 4, 1, 3)] and min(want) > 0
+    for v in views:
+        ra = a.metadata.export_rules(v[0], v[4:7] if v[0] == 2 else v[1:4], v[7:10], v[10:13] if v[0] == 2 else None)
+        rb = md.export_rules(v[0], v[4:7] if v[0] == 2 else v[1:4], v[7:10], v[10:13] if v[0] == 2 else None)
+        assert ra.shape[0] > 0 and np.array_equal(canon_rules(ra.cpu().numpy()), canon_rules(rb.cpu().numpy()))
     for sp in specs:
-        la, lb = a.metadata.getSpatialLocations(sp[3:6]), md.getSpatialLocations(sp[3:6])
+        la, lb = a.metadata.getSpatialLocations(sp[4:7]), md.getSpatialLocations(sp[4:7])
         assert torch.equal(la, lb)
-        ra = a.metadata.export_rules(1, sp[0:3], sp[6:9], sp[9:12])
-        rb = md.export_rules(1, sp[0:3], sp[6:9], sp[9:12])
+        ra = a.metadata.export_rules(1, sp[1:4], sp[7:10], sp[10:13])
+        rb = md.export_rules(1, sp[1:4], sp[7:10], sp[10:13])
         assert np.array_equal(canon_rules(ra.cpu().numpy()), canon_rules(rb.cpu().numpy()))
     # an entry that cannot be built (its input grid does not exist): error on wait and on finish, no hang
     with torch.no_grad():
@@ -442,7 +461,7 @@ def test_geometry_chain_on_the_library_thread_equals_the_calls_made_in_line(dev)
     geo.wait_stream(main)
     md.set_geometry_stream(geo.cuda_stream)
     try:
-        md.geometry_async_start([specs[0], [64, 64, 8, 32, 32, 4, 2, 2, 2, 2, 2, 2]], geo.cuda_stream)
+        md.geometry_async_start([specs[0], [1, 64, 64, 8, 32, 32, 4, 2, 2, 2, 2, 2, 2]], geo.cuda_stream)
         assert md.geometry_async_wait(0, main.cuda_stream) == want[0]
         with pytest.raises(D3DError, match="geometry thread"):
             md.geometry_async_wait(1, main.cuda_stream)
