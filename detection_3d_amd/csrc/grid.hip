@@ -1040,7 +1040,9 @@ namespace d3d {
 // while it waits.  The thread builds the listed rulebooks in order on the geometry stream and publishes, per entry,
 // the output site count and an event; the caller picks an entry up when it needs it (d3d_geometry_async_wait).
 struct GeoAsync {
-  std::thread th, th_views;                 // the grids (blocking read-backs) / the views behind them
+  std::thread th, th_views;                 // the grids (blocking read-backs) / the views behind them; started with the
+  bool threads_up = false, stop = false;    // first chain of this metadata and kept (a handle serves scene after scene)
+  int job = 0, job_done[2] = {0, 0};        // chains started / finished by each worker
   std::mutex mu;
   std::condition_variable cv;
   std::vector<std::array<int, 13>> specs;   // kind, in_size, out_size, filter, stride
@@ -1048,22 +1050,64 @@ struct GeoAsync {
   std::vector<hipEvent_t> ev;               // pool, reused from scene to scene
   std::vector<char> ready;                  // entry built (grids) / enqueued (views)
   int rc = 0, device = 0;
-  bool running = false;
   std::string err;
   hipStream_t stream = nullptr, view_stream = nullptr;
 };
-static void geo_async_join(d3d_meta *m) {
-  GeoAsync *g = (GeoAsync *)m->geo_async;
-  if (g && g->running) {
-    if (g->th.joinable()) g->th.join();
-    if (g->th_views.joinable()) g->th_views.join();
-    g->running = false;
+// publishes the outcome of entry i; returns false when the chain has failed (here or in the other worker)
+static bool geo_publish(GeoAsync *g, int i, int rc, int n_out) {
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (rc == D3D_OK) {
+    g->n_out[i] = n_out;
+    g->ready[i] = 1;
+  } else if (g->rc == D3D_OK) {
+    g->rc = rc;
+    g->err = g_err;
   }
+  g->cv.notify_all();
+  return g->rc == D3D_OK;
+}
+static int geo_begin(GeoAsync *g) {
+  if (hipSetDevice(g->device) == hipSuccess) return D3D_OK;
+  set_error("geometry thread: hipSetDevice(%d) failed", g->device);
+  return D3D_ERR_HIP;
+}
+static void geo_run_grids(d3d_meta *m, GeoAsync *g);   // (call d3d_conv_prepare & co, defined with the C entry points)
+static void geo_run_views(d3d_meta *m, GeoAsync *g);
+static void geo_worker(d3d_meta *m, GeoAsync *g, int which) {
+  int seen = 0;
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lk(g->mu);
+      g->cv.wait(lk, [&] { return g->stop || g->job != seen; });
+      if (g->stop) return;
+      seen = g->job;
+    }
+    if (which == 0) geo_run_grids(m, g);
+    else geo_run_views(m, g);
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->job_done[which] = seen;
+    g->cv.notify_all();
+  }
+}
+static void geo_async_join(d3d_meta *m) {      // waits until both workers have finished the chain that was started
+  GeoAsync *g = (GeoAsync *)m->geo_async;
+  if (!g || !g->threads_up) return;
+  std::unique_lock<std::mutex> lk(g->mu);
+  g->cv.wait(lk, [&] { return g->job_done[0] == g->job && g->job_done[1] == g->job; });
 }
 static void geo_async_free(d3d_meta *m) {
   GeoAsync *g = (GeoAsync *)m->geo_async;
   if (!g) return;
   geo_async_join(m);
+  if (g->threads_up) {
+    {
+      std::lock_guard<std::mutex> lk(g->mu);
+      g->stop = true;
+      g->cv.notify_all();
+    }
+    g->th.join();
+    g->th_views.join();
+  }
   for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
   delete g;
   m->geo_async = nullptr;
@@ -1586,6 +1630,59 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
   return D3D_OK;
 }
 
+}  // extern "C" (reopened below)
+
+namespace d3d {
+static void geo_run_grids(d3d_meta *m, GeoAsync *g) {      // the grids, in order; each one blocks on its count read-back
+  int rc = geo_begin(g);
+  const int n = (int)g->specs.size();
+  for (int i = 0; i < n; i++) {
+    if (g->specs[i][0] != 1) continue;
+    const int *sp = g->specs[i].data() + 1;
+    int n_out = 0;
+    if (rc == D3D_OK) rc = d3d_conv_prepare(m, sp, sp + 3, sp + 6, sp + 9, g->stream, &n_out, nullptr);
+    if (rc == D3D_OK && hipEventRecord(g->ev[i], g->stream) != hipSuccess) {
+      set_error("geometry thread: hipEventRecord failed");
+      rc = D3D_ERR_HIP;
+    }
+    if (!geo_publish(g, i, rc, n_out)) return;
+  }
+}
+static void geo_run_views(d3d_meta *m, GeoAsync *g) {      // the views: each behind the newest grid listed before it
+  int rc = geo_begin(g);
+  const int n = (int)g->specs.size();
+  int dep = -1;
+  for (int i = 0; i < n; i++) {
+    const int kind = g->specs[i][0];
+    if (kind == 1) {
+      dep = i;
+      continue;
+    }
+    if (dep >= 0) {
+      std::unique_lock<std::mutex> lk(g->mu);
+      g->cv.wait(lk, [&] { return g->ready[dep] || g->rc != D3D_OK; });
+      if (!g->ready[dep]) return;
+    }
+    const int *sp = g->specs[i].data() + 1;
+    hipStream_t on = g->view_stream;
+    if (rc == D3D_OK && dep >= 0 && hipStreamWaitEvent(on, g->ev[dep], 0) != hipSuccess) {
+      set_error("geometry thread: hipStreamWaitEvent failed");
+      rc = D3D_ERR_HIP;
+    }
+    if (rc == D3D_OK)
+      rc = kind == 0 ? d3d_subm_prepare(m, sp, sp + 6, on, nullptr)
+                     : d3d_deconv_prepare(m, sp, sp + 3, sp + 6, sp + 9, on, nullptr);
+    if (rc == D3D_OK && hipEventRecord(g->ev[i], on) != hipSuccess) {
+      set_error("geometry thread: hipEventRecord failed");
+      rc = D3D_ERR_HIP;
+    }
+    if (!geo_publish(g, i, rc, 0)) return;
+  }
+}
+}  // namespace d3d
+
+extern "C" {
+
 int d3d_geometry_async_start(d3d_meta *m, const int *specs, int n, void *stream, void *view_stream) {
   D3D_REQUIRE(m && (n == 0 || specs) && n >= 0 && n <= 128, "geometry_async_start: bad arguments");
   D3D_REQUIRE(m->geo_locked && (hipStream_t)stream == m->geo_stream,
@@ -1609,81 +1706,23 @@ int d3d_geometry_async_start(d3d_meta *m, const int *specs, int n, void *stream,
     D3D_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     g->ev.push_back(e);
   }
-  g->ready.assign(n, 0);
-  g->rc = D3D_OK;
-  g->err.clear();
-  g->stream = (hipStream_t)stream;
-  g->view_stream = (hipStream_t)view_stream;
-  D3D_HIP_CHECK(hipGetDevice(&g->device));
-  if (n == 0) return D3D_OK;
-  g->running = true;
-  // publishes the outcome of entry i; returns false when the chain has failed (here or in the other thread)
-  auto publish = [g](int i, int rc, int n_out) {
+  {
     std::lock_guard<std::mutex> lk(g->mu);
-    if (rc == D3D_OK) {
-      g->n_out[i] = n_out;
-      g->ready[i] = 1;
-    } else if (g->rc == D3D_OK) {
-      g->rc = rc;
-      g->err = d3d_last_error();
-    }
-    g->cv.notify_all();
-    return g->rc == D3D_OK;
-  };
-  auto begin = [g]() {
-    if (hipSetDevice(g->device) == hipSuccess) return (int)D3D_OK;
-    set_error("geometry thread: hipSetDevice(%d) failed", g->device);
-    return (int)D3D_ERR_HIP;
-  };
-  g->th = std::thread([m, g, publish, begin]() {     // the grids, in order; each one blocks on its count read-back
-    int rc = begin();
-    const int n = (int)g->specs.size();
-    for (int i = 0; i < n; i++) {
-      if (g->specs[i][0] != 1) continue;
-      const int *sp = g->specs[i].data() + 1;
-      int n_out = 0;
-      if (rc == D3D_OK) rc = d3d_conv_prepare(m, sp, sp + 3, sp + 6, sp + 9, g->stream, &n_out, nullptr);
-      if (rc == D3D_OK && hipEventRecord(g->ev[i], g->stream) != hipSuccess) {
-        set_error("geometry thread: hipEventRecord failed");
-        rc = D3D_ERR_HIP;
-      }
-      if (!publish(i, rc, n_out)) return;
-    }
-  });
-  bool any_view = false;
-  for (int i = 0; i < n; i++) any_view = any_view || g->specs[i][0] != 1;
-  if (any_view)
-    g->th_views = std::thread([m, g, publish, begin]() {   // the views: each behind the newest grid listed before it
-      int rc = begin();
-      const int n = (int)g->specs.size();
-      int dep = -1;
-      for (int i = 0; i < n; i++) {
-        const int kind = g->specs[i][0];
-        if (kind == 1) {
-          dep = i;
-          continue;
-        }
-        if (dep >= 0) {
-          std::unique_lock<std::mutex> lk(g->mu);
-          g->cv.wait(lk, [&] { return g->ready[dep] || g->rc != D3D_OK; });
-          if (!g->ready[dep]) return;
-        }
-        const int *sp = g->specs[i].data() + 1;
-        hipStream_t on = g->view_stream;
-        if (rc == D3D_OK && dep >= 0 && hipStreamWaitEvent(on, g->ev[dep], 0) != hipSuccess) {
-          set_error("geometry thread: hipStreamWaitEvent failed");
-          rc = D3D_ERR_HIP;
-        }
-        if (rc == D3D_OK)
-          rc = kind == 0 ? d3d_subm_prepare(m, sp, sp + 6, on, nullptr)
-                         : d3d_deconv_prepare(m, sp, sp + 3, sp + 6, sp + 9, on, nullptr);
-        if (rc == D3D_OK && hipEventRecord(g->ev[i], on) != hipSuccess) {
-          set_error("geometry thread: hipEventRecord failed");
-          rc = D3D_ERR_HIP;
-        }
-        if (!publish(i, rc, 0)) return;
-      }
-    });
+    g->ready.assign(n, 0);
+    g->rc = D3D_OK;
+    g->err.clear();
+    g->stream = (hipStream_t)stream;
+    g->view_stream = (hipStream_t)view_stream;
+  }
+  D3D_HIP_CHECK(hipGetDevice(&g->device));
+  if (!g->threads_up) {
+    g->th = std::thread(geo_worker, m, g, 0);
+    g->th_views = std::thread(geo_worker, m, g, 1);
+    g->threads_up = true;
+  }
+  std::lock_guard<std::mutex> lk(g->mu);
+  g->job++;
+  g->cv.notify_all();
   return D3D_OK;
 }
 
