@@ -119,6 +119,20 @@ def test_detector_is_deterministic_to_the_bit_at_full_size(scene, dev):
         fpn_net.TWO_LANE = True
     for a, b in zip(mid1["rpn_features"] + mid1["roi_features"], mid3["rpn_features"] + mid3["roi_features"]):
         assert torch.equal(a.features, b.features)
+    # every schedule of the pass -- grid chain on library threads with / without the rulebook views on a third stream
+    # (the default is the first), the chain driven by the launch thread on two streams, that with the views on a third --
+    # runs the same kernels on the same data: identical maps and detections
+    saved = (fpn_net.ASYNC_GEOMETRY, fpn_net.ASYNC_VIEWS, fpn_net.PLAN_LANE)
+    try:
+        for mode in ((True, False, False), (False, False, False), (False, False, True)):
+            fpn_net.ASYNC_GEOMETRY, fpn_net.ASYNC_VIEWS, fpn_net.PLAN_LANE = mode
+            r4, mid4 = model([coords, feats], return_intermediates=True)
+            for a, b in zip(mid1["rpn_features"] + mid1["roi_features"], mid4["rpn_features"] + mid4["roi_features"]):
+                assert torch.equal(a.features, b.features), mode
+            for k in ("bbox3d", "scores", "labels"):
+                assert torch.equal(r1[k], r4[k]), mode
+    finally:
+        fpn_net.ASYNC_GEOMETRY, fpn_net.ASYNC_VIEWS, fpn_net.PLAN_LANE = saved
     cloud = torch.from_numpy(pcl).to(dev)
     piped = BuildingPipeline(model, cfg, in_flight=2, device=dev).map([cloud, cloud, cloud])
     torch.cuda.synchronize()
