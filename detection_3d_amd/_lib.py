@@ -52,6 +52,8 @@ _SIGS = {
     "d3d_voxelize_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "d3d_input_layer_build": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, c_int_p, ctypes.c_int,
                                              ctypes.c_int, vp, c_int_p]),
+    "d3d_input_layer_build_prefetch": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, c_int_p, ctypes.c_int,
+                                                      ctypes.c_int, c_int_p, vp, c_int_p]),
     "d3d_input_layer_forward": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, vp]),
     "d3d_input_layer_export": (ctypes.c_int, [vp, vp, vp, vp]),
     "d3d_get_n_active": (ctypes.c_int, [vp, c_int_p, c_int_p]),

@@ -148,6 +148,14 @@ struct d3d_meta {
   int iota_n = 0;
   // pinned host words for size read-backs
   long *host_words = nullptr;
+  // neighbour table of the input grid started by d3d_input_layer_build_prefetch while the site count was read back
+  // (top of the geometry lane, which is shortened by it until d3d_meta_clear); consumed by d3d_subm_prepare
+  int32_t *pre_nbr = nullptr;
+  uint32_t *pre_mask = nullptr;
+  int pre_filt[3] = {0, 0, 0};
+  hipStream_t pre_stream = nullptr;
+  hipEvent_t count_ev = nullptr;   // marks the count copy, so that the host does not wait for the prefetch behind it
+  size_t arena_cap_full = 0;
   // the three maps above may be read by the caller's thread while the geometry thread (d3d_geometry_async_start) adds
   // to them: every lookup / insertion holds `mu` (map nodes do not move, so the pointers handed out stay valid)
   std::recursive_mutex mu;

@@ -565,13 +565,17 @@ __device__ __forceinline__ uint32_t plan_key(uint32_t m, int K) { return K <= 27
 __device__ __forceinline__ uint32_t plan_key_mask(uint32_t key, int K) { return K <= 27 ? (key & ((1u << K) - 1u)) : key; }
 
 static constexpr int kNbrSites = 64;
+// n_dev (may be null): the site count on the device, for a launch sized by an upper bound before the count is known
 __global__ __launch_bounds__(256) void k_subm_nbr(const int32_t *__restrict__ loc, int n, int fx, int fy,
                                                   int fz, const HashEntry *__restrict__ tab, int cap,
-                                                  int32_t *__restrict__ nbr, uint32_t *__restrict__ mask) {
+                                                  int32_t *__restrict__ nbr, uint32_t *__restrict__ mask,
+                                                  const int32_t *__restrict__ n_dev) {
   __shared__ uint32_t smask[kNbrSites];
   __shared__ int32_t sloc[kNbrSites * 4];
   const int K = fx * fy * fz;
   const int s0 = blockIdx.x * kNbrSites;
+  if (n_dev) n = *n_dev;
+  if (s0 >= n) return;
   const int ns = min(kNbrSites, n - s0);
   if (threadIdx.x < kNbrSites) smask[threadIdx.x] = 0;
   for (int e = threadIdx.x; e < ns * 4; e += 256) sloc[e] = loc[(size_t)s0 * 4 + e];
@@ -1039,6 +1043,20 @@ namespace d3d {
 // one blocking read-back of its site count, and a caller that builds the chain itself cannot enqueue feature kernels
 // while it waits.  The thread builds the listed rulebooks in order on the geometry stream and publishes, per entry,
 // the output site count and an event; the caller picks an entry up when it needs it (d3d_geometry_async_wait).
+// A new strided grid is complete (hash table, coordinates, site count) as soon as its count has been read back, before
+// the strided rulebook that d3d_conv_prepare builds with it: it is entered into the metadata then, and a geometry thread
+// may mark the moment on its stream (t_on_grid) so that the grid's views do not wait for the rulebook.
+static thread_local void (*t_on_grid)(void *, hipStream_t) = nullptr;
+static thread_local void *t_on_grid_arg = nullptr;
+static void publish_grid(d3d_meta *m, Grid &go, int n_out, const int *out_size, hipStream_t s) {
+  go.n = n_out;
+  {
+    D3D_LOCK(m);
+    m->grids[Size3{out_size[0], out_size[1], out_size[2]}] = go;
+  }
+  if (t_on_grid) t_on_grid(t_on_grid_arg, s);
+}
+
 struct GeoAsync {
   std::thread th, th_views;                 // the grids (blocking read-backs) / the views behind them; started with the
   bool threads_up = false, stop = false;    // first chain of this metadata and kept (a handle serves scene after scene)
@@ -1047,8 +1065,8 @@ struct GeoAsync {
   std::condition_variable cv;
   std::vector<std::array<int, 13>> specs;   // kind, in_size, out_size, filter, stride
   std::vector<int> n_out;
-  std::vector<hipEvent_t> ev;               // pool, reused from scene to scene
-  std::vector<char> ready;                  // entry built (grids) / enqueued (views)
+  std::vector<hipEvent_t> ev, gev;          // pools, reused from scene to scene: entry done / its grid complete
+  std::vector<char> ready, grid_ready;      // entry built (grids) / enqueued (views); grid of a kind-1 entry complete
   int rc = 0, device = 0;
   std::string err;
   hipStream_t stream = nullptr, view_stream = nullptr;
@@ -1109,6 +1127,7 @@ static void geo_async_free(d3d_meta *m) {
     g->th_views.join();
   }
   for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : g->gev) (void)hipEventDestroy(e);
   delete g;
   m->geo_async = nullptr;
 }
@@ -1129,7 +1148,7 @@ int d3d_meta_create(d3d_meta **out, size_t arena_bytes) {
     return D3D_ERR_HIP;
   }
   const size_t feat_bytes = (arena_bytes / 3) & ~size_t(255);   // second lane (see lane_arena)
-  m->arena.cap = arena_bytes - feat_bytes;
+  m->arena.cap = m->arena_cap_full = arena_bytes - feat_bytes;
   m->feat_arena.base = m->arena.base + m->arena.cap;
   m->feat_arena.cap = m->feat_cap_full = feat_bytes;
   e = hipHostMalloc((void **)&m->host_words, 16 * sizeof(long), hipHostMallocDefault);
@@ -1147,6 +1166,7 @@ int d3d_meta_destroy(d3d_meta *m) {
   geo_async_free(m);
   (void)hipFree(m->arena.base);
   (void)hipHostFree(m->host_words);
+  if (m->count_ev) (void)hipEventDestroy(m->count_ev);
   delete m;
   return D3D_OK;
 }
@@ -1155,6 +1175,9 @@ int d3d_meta_clear(d3d_meta *m) {
   geo_async_join(m);
   D3D_LOCK(m);
   m->arena.used = 0;
+  m->arena.cap = m->arena_cap_full;
+  m->pre_nbr = nullptr;
+  m->pre_mask = nullptr;
   m->feat_arena.used = 0;
   m->feat_arena.cap = m->feat_cap_full;
   m->plan_arena = Arena();
@@ -1236,6 +1259,12 @@ int d3d_voxelize(const float *pcl, int n, int nfeat, double scale, const int *fu
 
 int d3d_input_layer_build(d3d_meta *m, const int64_t *coords, int n, int ncols, const int *size,
                           int batch_size, int mode, void *stream, int *n_active_host) {
+  return d3d_input_layer_build_prefetch(m, coords, n, ncols, size, batch_size, mode, nullptr, stream, n_active_host);
+}
+
+int d3d_input_layer_build_prefetch(d3d_meta *m, const int64_t *coords, int n, int ncols, const int *size,
+                                   int batch_size, int mode, const int *prefetch_filter, void *stream,
+                                   int *n_active_host) {
   hipStream_t s = (hipStream_t)stream;
   (void)batch_size;
   D3D_REQUIRE(m && size && n_active_host, "null argument");
@@ -1286,7 +1315,31 @@ int d3d_input_layer_build(d3d_meta *m, const int64_t *coords, int n, int ncols, 
     hipLaunchKernelGGL(k_assign_input_sites, grid1d(n), dim3(256), 0, s, coords, n, ncols, pslot, flag, rank, tab, loc);
     D3D_LAUNCH_CHECK();
     D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[0], total, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    D3D_HIP_CHECK(hipStreamSynchronize(s));
+    bool prefetched = false;
+    if (prefetch_filter) {
+      // The neighbour table of the submanifold rulebook the caller will ask for first (hash probes of every site,
+      // the longest kernel of a rulebook) starts now, sized by the point count and reading the site count on the
+      // device, so that it runs while the host waits for the count and walks back up to d3d_subm_prepare.  It lives at
+      // the top of the geometry lane, which stays that much shorter for the scene.
+      const int K = prefetch_filter[0] * prefetch_filter[1] * prefetch_filter[2];
+      const size_t raw = (((size_t)n * K + 1) * sizeof(int32_t) + 255) & ~size_t(255);
+      const size_t msk = ((size_t)n * sizeof(uint32_t) + 511) & ~size_t(255);
+      if (K > 1 && K <= 32 && A.used + raw + msk + (64u << 20) < A.cap) {
+        A.cap = (A.cap - raw - msk) & ~size_t(255);
+        m->pre_mask = (uint32_t *)(A.base + A.cap);
+        m->pre_nbr = (int32_t *)(A.base + A.cap + msk);
+        for (int d = 0; d < 3; d++) m->pre_filt[d] = prefetch_filter[d];
+        m->pre_stream = s;
+        if (!m->count_ev) D3D_HIP_CHECK(hipEventCreateWithFlags(&m->count_ev, hipEventDisableTiming));
+        D3D_HIP_CHECK(hipEventRecord(m->count_ev, s));          // the host waits for the count, not for the table
+        hipLaunchKernelGGL(k_subm_nbr, grid1d(n, kNbrSites), dim3(256), 0, s, loc, n, prefetch_filter[0],
+                           prefetch_filter[1], prefetch_filter[2], tab, g.cap, m->pre_nbr, m->pre_mask, total);
+        D3D_LAUNCH_CHECK();
+        prefetched = true;
+      }
+    }
+    if (prefetched) D3D_HIP_CHECK(hipEventSynchronize(m->count_ev));
+    else D3D_HIP_CHECK(hipStreamSynchronize(s));
     n_active = (int)*(int32_t *)&m->host_words[0];
     A.used = mark;
   }
@@ -1484,12 +1537,18 @@ int d3d_subm_prepare(d3d_meta *m, const int *size, const int *filt, void *stream
       p.blkmask = blkmask;
       if (npos) hipLaunchKernelGGL(k_identity_plan, grid1d(npos), dim3(256), 0, s, rows, nbrT, blkmask, g->n, npos, p.n_blk);
       D3D_LAUNCH_CHECK();
+    } else if (m->pre_nbr && s == m->pre_stream && g->size[0] == m->in_size[0] && g->size[1] == m->in_size[1] &&
+               g->size[2] == m->in_size[2] && filt[0] == m->pre_filt[0] && filt[1] == m->pre_filt[1] &&
+               filt[2] == m->pre_filt[2]) {
+      // the table d3d_input_layer_build_prefetch started on this stream
+      int rc = finalize_plan(m, m->pre_nbr, g->n, K, p, s, m->pre_mask);
+      if (rc) return rc;
     } else {
       int32_t *nbr = (int32_t *)(A.base + ((A.cap - raw_bytes) & ~size_t(255)));
       uint32_t *mask = (uint32_t *)((char *)nbr - (((size_t)g->n * 4 + 511) & ~size_t(255)));
       if (g->n)
         hipLaunchKernelGGL(k_subm_nbr, grid1d(g->n, kNbrSites), dim3(256), 0, s, g->loc, g->n, filt[0], filt[1], filt[2],
-                           g->tab, g->cap, nbr, mask);
+                           g->tab, g->cap, nbr, mask, (const int32_t *)nullptr);
       D3D_LAUNCH_CHECK();
       int rc;
       {
@@ -1579,6 +1638,7 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
       D3D_HIP_CHECK(hipStreamSynchronize(s));
       n_out = (int)*(int32_t *)&m->host_words[1];
       A.used = mark;
+      publish_grid(m, go, n_out, out_size, s);
       int rc = finalize_plan(m, nbr_fwd, n_out, K, p, s, nullptr);
       if (rc) return rc;
     } else if (n_entries > 0) {
@@ -1604,6 +1664,7 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
       D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[1], total, sizeof(int32_t), hipMemcpyDeviceToHost, s));
       D3D_HIP_CHECK(hipStreamSynchronize(s));
       n_out = (int)*(int32_t *)&m->host_words[1];
+      publish_grid(m, go, n_out, out_size, s);
       D3D_HIP_CHECK(fill_ones(nbr_fwd, sizeof(int32_t) * ((size_t)n_out * K + 1), s));
       hipLaunchKernelGGL(k_conv_fill, grid1d(n_entries), dim3(256), 0, s, gi->loc, n_entries, geo, K, eslot, tab, nbr_fwd, nbr_dec);
       D3D_LAUNCH_CHECK();
@@ -1611,12 +1672,11 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
       rc = finalize_plan(m, nbr_fwd, n_out, K, p, s, nullptr);
       if (rc) return rc;
     } else {
+      publish_grid(m, go, 0, out_size, s);
       int rc = finalize_plan(m, nullptr, 0, K, p, s, nullptr);
       if (rc) return rc;
     }
-    go.n = n_out;
-    D3D_LOCK(m);   // the finished grid, raw table and rulebook become visible together
-    m->grids[Size3{out_size[0], out_size[1], out_size[2]}] = go;
+    D3D_LOCK(m);   // the raw table and the rulebook become visible together (the grid already is: publish_grid)
     StridedRaw raw;
     raw.nbr_dec = nbr_dec;
     raw.n_in = n_in;
@@ -1640,7 +1700,20 @@ static void geo_run_grids(d3d_meta *m, GeoAsync *g) {      // the grids, in orde
     if (g->specs[i][0] != 1) continue;
     const int *sp = g->specs[i].data() + 1;
     int n_out = 0;
+    struct Mark {
+      GeoAsync *g;
+      int i;
+    } mk = {g, i};
+    t_on_grid_arg = &mk;
+    t_on_grid = [](void *a, hipStream_t on) {       // the grid exists: its submanifold views may start
+      Mark *k = (Mark *)a;
+      if (hipEventRecord(k->g->gev[k->i], on) != hipSuccess) return;   // (then the views wait for the whole entry)
+      std::lock_guard<std::mutex> lk(k->g->mu);
+      k->g->grid_ready[k->i] = 1;
+      k->g->cv.notify_all();
+    };
     if (rc == D3D_OK) rc = d3d_conv_prepare(m, sp, sp + 3, sp + 6, sp + 9, g->stream, &n_out, nullptr);
+    t_on_grid = nullptr;
     if (rc == D3D_OK && hipEventRecord(g->ev[i], g->stream) != hipSuccess) {
       set_error("geometry thread: hipEventRecord failed");
       rc = D3D_ERR_HIP;
@@ -1658,14 +1731,17 @@ static void geo_run_views(d3d_meta *m, GeoAsync *g) {      // the views: each be
       dep = i;
       continue;
     }
+    // a submanifold view needs the grid only; a deconvolution view the strided rulebook built with it
+    bool early = false;
     if (dep >= 0) {
       std::unique_lock<std::mutex> lk(g->mu);
-      g->cv.wait(lk, [&] { return g->ready[dep] || g->rc != D3D_OK; });
-      if (!g->ready[dep]) return;
+      g->cv.wait(lk, [&] { return g->ready[dep] || (kind == 0 && g->grid_ready[dep]) || g->rc != D3D_OK; });
+      if (!g->ready[dep] && !(kind == 0 && g->grid_ready[dep])) return;
+      early = !g->ready[dep];
     }
     const int *sp = g->specs[i].data() + 1;
     hipStream_t on = g->view_stream;
-    if (rc == D3D_OK && dep >= 0 && hipStreamWaitEvent(on, g->ev[dep], 0) != hipSuccess) {
+    if (rc == D3D_OK && dep >= 0 && hipStreamWaitEvent(on, early ? g->gev[dep] : g->ev[dep], 0) != hipSuccess) {
       set_error("geometry thread: hipStreamWaitEvent failed");
       rc = D3D_ERR_HIP;
     }
@@ -1702,13 +1778,16 @@ int d3d_geometry_async_start(d3d_meta *m, const int *specs, int n, void *stream,
     for (int j = 0; j < 13; j++) g->specs[i][j] = specs[i * 13 + j];
   g->n_out.assign(n, 0);
   while ((int)g->ev.size() < n) {
-    hipEvent_t e;
+    hipEvent_t e, e2;
     D3D_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     g->ev.push_back(e);
+    D3D_HIP_CHECK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+    g->gev.push_back(e2);
   }
   {
     std::lock_guard<std::mutex> lk(g->mu);
     g->ready.assign(n, 0);
+    g->grid_ready.assign(n, 0);
     g->rc = D3D_OK;
     g->err.clear();
     g->stream = (hipStream_t)stream;

@@ -338,11 +338,14 @@ def _coords_to_device(coords, device):
 _TLS = threading.local()
 
 
-def set_after_input_build(hook):
+def set_after_input_build(hook, prefetch_filter=None):
     """hook(metadata, spatial_size) is called by this thread's next InputLayer_updateOutput calls between the grid
     build (whose site count has just been read back) and the feature pass of the input layer -- where a caller can
-    start the level-0 rulebook on another stream (FPN_Net._forward_two_lane).  None removes it."""
+    start the level-0 rulebook on another stream (FPN_Net._forward_two_lane).  None removes it.
+    prefetch_filter: the filter of the submanifold rulebook the caller will prepare first on the same stream; its
+    neighbour table is then probed while the host waits for the site count (d3d_input_layer_build_prefetch)."""
     _TLS.after_input_build = hook
+    _TLS.input_prefetch = None if (hook is None or prefetch_filter is None) else _size3(prefetch_filter)
 
 
 def InputLayer_prepare(m):
@@ -358,8 +361,10 @@ def InputLayer_updateOutput(m, spatial_size, input_coords, input_features, outpu
     coords = _coords_to_device(input_coords, dev)
     n, ncols = coords.shape
     na = ctypes.c_int(0)
-    check(lib().d3d_input_layer_build(m._h, ptr(coords), n, ncols, ints(_size3(spatial_size)),
-                                      int(batch_size), int(mode), stream_of(), ctypes.byref(na)))
+    pre = getattr(_TLS, "input_prefetch", None)
+    check(lib().d3d_input_layer_build_prefetch(m._h, ptr(coords), n, ncols, ints(_size3(spatial_size)),
+                                               int(batch_size), int(mode), ints(pre) if pre is not None else None,
+                                               stream_of(), ctypes.byref(na)))
     m._in_active = na.value
     hook = getattr(_TLS, "after_input_build", None)
     if hook is not None:

@@ -142,8 +142,8 @@ class FPN_Net(torch.nn.Module):
 
     def _geometry_specs(self, size0, views=False):
         """The d3d_conv_prepare calls of the pyramid in the order _geometry_steps makes them, as rows of 13 ints
-        (kind 1, in_size, out_size, filter, stride), and for every level the index of the last row it needs before its
-        convolutions may be enqueued (-1: none).  With `views` the rulebooks that are views of a grid are listed too
+        (kind 1, in_size, out_size, filter, stride), and for every level the rows it needs before its convolutions may be
+        enqueued: (its last grid row, its 3x3x3 view row), -1 = none.  With `views` the rulebooks that are views of a grid are listed too
         (what _geometry_steps builds with full=True): the 3x3x3 submanifold rulebook (kind 0) of every level but the
         first right behind its grid -- the row a level then waits for -- and, after all grids, the lateral 1x1x1
         rulebooks and the deconvolution views (kind 2) of the top-down path.
@@ -171,12 +171,16 @@ class FPN_Net(torch.nn.Module):
                 conv = pro2d[k]
                 out = (size - conv.filter_size) // conv.filter_stride + 1
                 specs.append([1] + size.tolist() + out.tolist() + conv.filter_size.tolist() + conv.filter_stride.tolist())
+            grid_row = len(specs) - 1 if (k > 0 or k in pro2d) else -1     # the level's last grid / strided rulebook
+            view_row = -1
             if views:
                 if k > 0:           # (level 0's is built by the caller while the point lists are sorted)
                     specs.append([0] + size.tolist() + size.tolist() + three + one)
+                    view_row = len(specs) - 1
                 if k >= lowest_up:
                     later.append([0] + size.tolist() + size.tolist() + one + one)
-            last.append(len(specs) - 1 if (k > 0 or k in pro2d) else -1)
+            # a level waits for both: its 3x3x3 view starts as soon as the GRID exists, before the strided rulebook
+            last.append((grid_row, view_row))
         specs += later
         return specs, last, len(specs) - 1
 
@@ -219,7 +223,8 @@ class FPN_Net(torch.nn.Module):
             state["md"] = md
             main.wait_event(plan0)
 
-        scn.SCN.set_after_input_build(after_input_build)
+        # (the neighbour table of level 0's 3x3x3 rulebook is probed while the input grid's site count is read back)
+        scn.SCN.set_after_input_build(after_input_build, prefetch_filter=(3,) * self.dimension)
         try:
             net = self.layers_in[0](net0)                   # input layer: grid of level 0
         finally:
@@ -233,9 +238,10 @@ class FPN_Net(torch.nn.Module):
             def lane(k):
                 _tmark("host enters", k, host=True)
                 _tmark("main arrives", k, main)
-                idx = state["all"] if k >= n_scales else state["last"][k]
-                if idx >= 0 and (k < n_scales or plan is not None):
-                    md.geometry_async_wait(idx, main.cuda_stream)
+                rows = (state["all"],) if k >= n_scales else state["last"][k]
+                for idx in rows:
+                    if idx >= 0 and (k < n_scales or plan is not None):
+                        md.geometry_async_wait(idx, main.cuda_stream)
                 _tmark("main continues", k, main)
                 _tmark("host leaves", k, host=True)
 

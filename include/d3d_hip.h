@@ -98,6 +98,14 @@ size_t d3d_voxelize_scratch_bytes(int n);
 int d3d_input_layer_build(d3d_meta *m, const int64_t *coords, int n, int ncols,
                           const int *spatial_size_host, int batch_size, int mode, void *stream,
                           int *n_active_host);
+/* The same, and while the host waits for the site count the neighbour table of the submanifold rulebook
+ * (spatial_size, prefetch_filter) -- the one d3d_subm_prepare is asked for first -- is already being probed on
+ * `stream`, sized by n and reading the count on the device; d3d_subm_prepare on the same stream picks it up.
+ * prefetch_filter NULL: plain d3d_input_layer_build.  (The reference builds that rulebook inside the first
+ * convolution's forward, Metadata.cpp:430-443.)                                                              */
+int d3d_input_layer_build_prefetch(d3d_meta *m, const int64_t *coords, int n, int ncols,
+                                   const int *spatial_size_host, int batch_size, int mode,
+                                   const int *prefetch_filter_host, void *stream, int *n_active_host);
 /* The per-site point lists d3d_input_layer_forward / _backward read (IOLayersRules.h:19-125 builds them with the
  * grid) are built by the first call that needs them, on ITS stream; this builds them explicitly, e.g. on a side stream
  * while the caller's stream already probes the level-0 rulebook.                                               */

@@ -106,7 +106,7 @@ def test_async_geometry_specs_are_the_grid_calls_of_the_schedule(monkeypatch, na
     assert len(last) == len(net.m_downs) and last_all == len(specs) - 1
     for k, n_after in enumerate(per_level):
         before = per_level[k - 1] if k else 0
-        assert last[k] == (n_after - 1 if n_after > before else -1)
+        assert last[k] == ((n_after - 1 if n_after > before else -1), -1)
     # with the views: the same grids in the same order, every level waits for its 3x3x3 rulebook (listed right behind
     # its grids), and the rulebooks of the top-down path -- the `full` ones of _geometry_steps -- come last
     v, vlast, vall = net._geometry_specs(Net0.spatial_size, views=True)
@@ -119,8 +119,10 @@ def test_async_geometry_specs_are_the_grid_calls_of_the_schedule(monkeypatch, na
     got = [(s[0], tuple(s[1:4]), tuple(s[7:10])) if s[0] == 0 else (2, tuple(s[1:4]), tuple(s[4:7])) for s in v if s[0] != 1]
     size0 = tuple(cfg.SPARSE3D.VOXEL_FULL_SCALE)
     assert sorted(got + [(0, size0, (3, 3, 3))]) == sorted(full)      # (level 0's 3x3x3 is the caller's)
-    for k, idx in enumerate(vlast):
+    for k, (grid_row, idx) in enumerate(vlast):
         if k == 0:
+            assert idx == -1
             continue
-        assert v[idx][0] == 0 and tuple(v[idx][7:10]) == (3, 3, 3)
+        assert v[idx][0] == 0 and tuple(v[idx][7:10]) == (3, 3, 3) and v[grid_row][0] == 1 and grid_row < idx
         assert all(s[0] == 1 or tuple(s[7:10]) == (3, 3, 3) for s in v[:idx + 1])
+        assert all(s[0] != 1 for s in v[grid_row + 1:idx + 1])          # the level's last grid row
