@@ -114,15 +114,16 @@ __global__ __launch_bounds__(256) void k_roi_dense(const float *__restrict__ inp
 // level is a few MB; what matters is the number of loads in flight, not bytes.
 // layout 0: out[n][c][ph][pw][pz] (the reference's); layout 1: out[n][ph][pw][c][pz] (rows of the box head's
 // [1,1,pz] convolution seen as a GEMM).  roi_levels (optional): only RoIs with roi_levels[i] == level are pooled.
-static constexpr int kRoiG = 8;
+static constexpr int kRoiG = 4;   // 4 bins per group and 4 waves per SIMD (128 VGPRs, 4 spilled): 286 us for the bench's 1000 RoIs;
+                                 // 8 bins at 3 waves (164 VGPRs) 368 us, 4 bins at 3 waves 357 us, 4 bins at 5 waves: 32 spills
 static constexpr int kRoiCch = 128;
 __device__ __forceinline__ void roi_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-static constexpr int kRoiWaves = 4;  // waves per RoI (8 measured the same: the kernel is bandwidth-, not latency-bound)
-__global__ __launch_bounds__(kRoiWaves * 64) void k_roi_sparse(
+static constexpr int kRoiWaves = 4;  // waves per RoI (8 measured the same; what helps is waves per SIMD, see kRoiG)
+__global__ __launch_bounds__(kRoiWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_roi_sparse(
     const HashEntry *__restrict__ tab, int cap, const float *__restrict__ feats, int C, int H, int W, int Z,
     const int32_t *__restrict__ extent, const float *__restrict__ rois, const int32_t *__restrict__ roi_levels,
     int level, float spatial_scale, int PH, int PW, int PZ, int sampling_ratio, int layout, float *__restrict__ out) {
