@@ -66,20 +66,36 @@ __device__ __forceinline__ bool seg_intersect(const float *p1, const float *p2, 
   return true;
 }
 
+// The point list (up to 24 points) and the sort keys of inter() are indexed at run time: as private arrays they live in
+// scratch memory.  PrivatePts is that form; LdsPts keeps them in a column of LDS the caller provides (element i of
+// thread t at base[i * stride + t]) -- same operations in the same order.
+struct PrivatePts {
+  float p[48], v[24];
+  __device__ __forceinline__ float &pt(int i) { return p[i]; }
+  __device__ __forceinline__ float &key(int i) { return v[i]; }
+};
+struct LdsPts {
+  float *base;
+  int stride;
+  __device__ __forceinline__ float &pt(int i) { return base[i * stride]; }
+  __device__ __forceinline__ float &key(int i) { return base[(48 + i) * stride]; }
+};
+static constexpr int kLdsPtsFloats = 72;
+
 // inter() of nms_gpu.py:381-395 on precomputed corners: q1 = rbbox1, q2 = rbbox2.
-__device__ double quad_inter_f32(const Quad &q1, const Quad &q2) {
-  float pts[48];
+template <class Pts>
+__device__ double quad_inter_f32(const Quad &q1, const Quad &q2, Pts B) {
   int num = 0;
   // nms_gpu.py:331-352
   for (int i = 0; i < 4; i++) {
     if (point_in_quad(q1.p[2 * i], q1.p[2 * i + 1], q2.p)) {
-      pts[num * 2] = q1.p[2 * i];
-      pts[num * 2 + 1] = q1.p[2 * i + 1];
+      B.pt(num * 2) = q1.p[2 * i];
+      B.pt(num * 2 + 1) = q1.p[2 * i + 1];
       num++;
     }
     if (point_in_quad(q2.p[2 * i], q2.p[2 * i + 1], q1.p)) {
-      pts[num * 2] = q2.p[2 * i];
-      pts[num * 2 + 1] = q2.p[2 * i + 1];
+      B.pt(num * 2) = q2.p[2 * i];
+      B.pt(num * 2 + 1) = q2.p[2 * i + 1];
       num++;
     }
   }
@@ -87,58 +103,59 @@ __device__ double quad_inter_f32(const Quad &q1, const Quad &q2) {
   for (int i = 0; i < 4; i++)
     for (int j = 0; j < 4; j++)
       if (seg_intersect(q1.p, q2.p, i, j, tmp)) {
-        pts[num * 2] = tmp[0];
-        pts[num * 2 + 1] = tmp[1];
+        B.pt(num * 2) = tmp[0];
+        B.pt(num * 2 + 1) = tmp[1];
         num++;
       }
   if (num < 3) return 0.0;
   // nms_gpu.py:182-219
   float cx = 0.f, cy = 0.f;
   for (int i = 0; i < num; i++) {
-    cx += pts[2 * i];
-    cy += pts[2 * i + 1];
+    cx += B.pt(2 * i);
+    cy += B.pt(2 * i + 1);
   }
   cx = (float)((double)cx / num);
   cy = (float)((double)cy / num);
-  float vs[24];
   for (int i = 0; i < num; i++) {
-    float v0 = pts[2 * i] - cx, v1 = pts[2 * i + 1] - cy;
+    float v0 = B.pt(2 * i) - cx, v1 = B.pt(2 * i + 1) - cy;
     const float d = sqrtf(v0 * v0 + v1 * v1);
     v0 = v0 / d;
     v1 = v1 / d;
     if (v1 < 0) v0 = -2 - v0;
-    vs[i] = v0;
+    B.key(i) = v0;
   }
   for (int i = 1; i < num; i++) {
-    if (vs[i - 1] > vs[i]) {
-      const float temp = vs[i], tx = pts[2 * i], ty = pts[2 * i + 1];
+    if (B.key(i - 1) > B.key(i)) {
+      const float temp = B.key(i), tx = B.pt(2 * i), ty = B.pt(2 * i + 1);
       int j = i;
-      while (j > 0 && vs[j - 1] > temp) {
-        vs[j] = vs[j - 1];
-        pts[j * 2] = pts[j * 2 - 2];
-        pts[j * 2 + 1] = pts[j * 2 - 1];
+      while (j > 0 && B.key(j - 1) > temp) {
+        B.key(j) = B.key(j - 1);
+        B.pt(j * 2) = B.pt(j * 2 - 2);
+        B.pt(j * 2 + 1) = B.pt(j * 2 - 1);
         j--;
       }
-      vs[j] = temp;
-      pts[j * 2] = tx;
-      pts[j * 2 + 1] = ty;
+      B.key(j) = temp;
+      B.pt(j * 2) = tx;
+      B.pt(j * 2 + 1) = ty;
     }
   }
   // nms_gpu.py:166-179
   double area = 0.0;
   for (int i = 0; i < num - 2; i++) {
-    const float *a = pts, *b = pts + 2 * i + 2, *c = pts + 2 * i + 4;
-    const float v = (a[0] - c[0]) * (b[1] - c[1]) - (a[1] - c[1]) * (b[0] - c[0]);
+    const float a0 = B.pt(0), a1 = B.pt(1), b0 = B.pt(2 * i + 2), b1 = B.pt(2 * i + 3), c0 = B.pt(2 * i + 4),
+                c1 = B.pt(2 * i + 5);
+    const float v = (a0 - c0) * (b1 - c1) - (a1 - c1) * (b0 - c0);
     area += fabs((double)v / 2.0);
   }
   return area;
 }
 
 // devRotateIoUEval (nms_gpu.py:552-570): rbox1 = (q1, dims d1a x d1b), rbox2 likewise.
+template <class Pts = PrivatePts>
 __device__ __forceinline__ float iou_eval(const Quad &q1, float d1a, float d1b, const Quad &q2,
-                                          float d2a, float d2b, int criterion) {
+                                          float d2a, float d2b, int criterion, Pts B = Pts()) {
   const float area1 = d1a * d1b, area2 = d2a * d2b;
-  const double ai = quad_inter_f32(q1, q2);
+  const double ai = quad_inter_f32(q1, q2, B);
   if (criterion == -1) return (float)(ai / ((double)(area1 + area2) - ai));
   if (criterion == 0) return (float)(ai / area1);
   if (criterion == 1) return (float)(ai / area2);
@@ -151,45 +168,55 @@ __device__ __forceinline__ float iou_eval(const Quad &q1, float d1a, float d1b, 
 }
 
 // fp64 Sutherland-Hodgman clip of quad P by quad Q (both fp32 corners); returns the area.
-__device__ double quad_inter_f64(const float *P, const float *Q) {
-  double a[32], b[32];
+// The two vertex lists (a quad clipped by four half-planes has at most 8 vertices) are indexed at run time; as private
+// arrays they end up in scratch memory (528 B per lane, every access a round trip), so the caller hands in a column of
+// LDS instead: element i of list l of thread t is buf[(l * 16 + i) * stride + t].  Same operations in the same order.
+__device__ __forceinline__ double quad_inter_f64(const float *P, const float *Q, double *buf, int stride) {
+  double *a = buf, *b = buf + 16 * stride;
   int na = 4;
-  for (int i = 0; i < 8; i++) a[i] = P[i];
+#pragma unroll
+  for (int i = 0; i < 8; i++) a[i * stride] = P[i];
   double sq = 0;
+#pragma unroll
   for (int i = 0; i < 4; i++) {
     const int j = (i + 1) & 3;
     sq += (double)Q[2 * i] * Q[2 * j + 1] - (double)Q[2 * j] * Q[2 * i + 1];
   }
   const double sgn = sq >= 0 ? 1.0 : -1.0;
-  for (int e = 0; e < 4 && na > 0; e++) {
+#pragma unroll
+  for (int e = 0; e < 4; e++) {      // (unrolled: Q is then indexed statically and stays in registers)
+    if (na <= 0) break;
     const double x1 = Q[2 * e], y1 = Q[2 * e + 1];
     const double x2 = Q[2 * ((e + 1) & 3)], y2 = Q[2 * ((e + 1) & 3) + 1];
     int nb = 0;
     for (int i = 0; i < na; i++) {
       const int j = (i + 1) % na;
-      const double cx = a[2 * i], cy = a[2 * i + 1], nx = a[2 * j], ny = a[2 * j + 1];
+      const double cx = a[(2 * i) * stride], cy = a[(2 * i + 1) * stride], nx = a[(2 * j) * stride],
+                   ny = a[(2 * j + 1) * stride];
       const double dc = sgn * ((x2 - x1) * (cy - y1) - (y2 - y1) * (cx - x1));
       const double dn = sgn * ((x2 - x1) * (ny - y1) - (y2 - y1) * (nx - x1));
       if (dc >= 0) {
-        b[2 * nb] = cx;
-        b[2 * nb + 1] = cy;
+        b[(2 * nb) * stride] = cx;
+        b[(2 * nb + 1) * stride] = cy;
         nb++;
       }
       if ((dc >= 0) != (dn >= 0)) {
         const double t = dc / (dc - dn);
-        b[2 * nb] = cx + t * (nx - cx);
-        b[2 * nb + 1] = cy + t * (ny - cy);
+        b[(2 * nb) * stride] = cx + t * (nx - cx);
+        b[(2 * nb + 1) * stride] = cy + t * (ny - cy);
         nb++;
       }
     }
     na = nb;
-    for (int i = 0; i < 2 * nb; i++) a[i] = b[i];
+    double *tmp = a;   // the clipped list is the next edge's input
+    a = b;
+    b = tmp;
   }
   if (na < 3) return 0.0;
   double s = 0;
   for (int i = 0; i < na; i++) {
     const int j = (i + 1) % na;
-    s += a[2 * i] * a[2 * j + 1] - a[2 * j] * a[2 * i + 1];
+    s += a[(2 * i) * stride] * a[(2 * j + 1) * stride] - a[(2 * j) * stride] * a[(2 * i + 1) * stride];
   }
   return fabs(s) * 0.5;
 }
@@ -390,9 +417,19 @@ __global__ __launch_bounds__(256) void k_nms_pairs(const NmsBox *__restrict__ re
     base += (unsigned int)__popcll(bal[u]);
   }
 }
-__global__ __launch_bounds__(256) void k_nms_eval(const NmsBox *__restrict__ rec, const int2 *__restrict__ pairs,
-                                                  const unsigned int *__restrict__ n_pairs, int n_max, int ncb,
-                                                  float thresh, unsigned long long *__restrict__ mask) {
+static constexpr int kEvalThreads = 128;   // x 32 doubles of LDS per thread (the clip's two vertex lists) = 32 KB
+__global__ __launch_bounds__(kEvalThreads) void k_nms_eval(const NmsBox *__restrict__ rec, const int2 *__restrict__ pairs,
+                                                           const unsigned int *__restrict__ n_pairs, int n_max, int ncb,
+                                                           float thresh, unsigned long long *__restrict__ mask) {
+  // one column per lane, in a region per WAVE: the fp32 gate's point list (72 floats), then the fp64 clip's two vertex
+  // lists (32 doubles) reuse it.  The two layouts overlap in memory, which is safe only inside a wave (its lanes run
+  // the gate of a pair together, then some of them the clip); another wave may be in the other phase.
+  constexpr int kColBytes = kLdsPtsFloats * 4 > 256 ? kLdsPtsFloats * 4 : 256;
+  __shared__ __attribute__((aligned(16))) char sm[kEvalThreads * kColBytes];
+  char *region = sm + (threadIdx.x >> 6) * (64 * kColBytes);
+  const int lane = threadIdx.x & 63;
+  double *clip = reinterpret_cast<double *>(region) + lane;
+  const LdsPts pts = {reinterpret_cast<float *>(region) + lane, 64};
   const unsigned int total = *n_pairs;
   for (unsigned int p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
     int2 ij = pairs[p];
@@ -400,7 +437,7 @@ __global__ __launch_bounds__(256) void k_nms_eval(const NmsBox *__restrict__ rec
     ij.x &= (1 << kNmsIdxBits) - 1;
     const NmsBox rb = rec[seg0 + ij.x], cb = rec[seg0 + ij.y];
     // gate = boxes_iou_3d(dets, dets)[i, j] > 0 (nms_cpu.py:35, spconv nms.h)
-    float v = iou_eval(cb.q, cb.d0, cb.d1, rb.q, rb.d0, rb.d1, -1);
+    float v = iou_eval(cb.q, cb.d0, cb.d1, rb.q, rb.d0, rb.d1, -1, pts);
     bool same = true;
 #pragma unroll
     for (int d = 0; d < 5; d++) same = same && (fabsf(rb.raw[d] - cb.raw[d]) < (float)1e-6);
@@ -409,7 +446,7 @@ __global__ __launch_bounds__(256) void k_nms_eval(const NmsBox *__restrict__ rec
     const float common = fmaxf(cb.z1, rb.z1) - fminf(cb.z0, rb.z0);
     v = v * (overlap / common);
     if (!(v > 0.0f)) continue;
-    const double ia = quad_inter_f64(rb.q.p, cb.q.p);
+    const double ia = quad_inter_f64(rb.q.p, cb.q.p, clip, 64);
     if (!(ia > 0)) continue;
     const double ua = rb.area + cb.area - ia;
     if (ua > 0 && ia / ua >= (double)thresh)
@@ -596,7 +633,7 @@ int d3d_rotate_nms_3d_batched(const float *boxes, const int32_t *order, int stri
   D3D_HIP_CHECK(hipMemsetAsync(mask, 0, (((size_t)B * n * ncb * 8 + 255) & ~size_t(255)) + 256, s));  // masks + pair counter
   hipLaunchKernelGGL(k_nms_prep, dim3((n + 127) / 128, B), dim3(128), 0, s, boxes, g, min_yx, min_z, rec);
   hipLaunchKernelGGL(k_nms_pairs, dim3(ncb, ncb, B), dim3(256), 0, s, rec, g, pairs, n_pairs);
-  hipLaunchKernelGGL(k_nms_eval, dim3(512), dim3(256), 0, s, rec, pairs, n_pairs, n, ncb, thresh, mask);
+  hipLaunchKernelGGL(k_nms_eval, dim3(1024), dim3(kEvalThreads), 0, s, rec, pairs, n_pairs, n, ncb, thresh, mask);
   hipLaunchKernelGGL(k_nms_sweep, dim3(B), dim3(64), 0, s, mask, g, ncb, max_keep > 0 ? max_keep : n, keep, n_keep);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
