@@ -151,11 +151,13 @@ __device__ double quad_inter_f32(const Quad &q1, const Quad &q2, Pts B) {
 }
 
 // devRotateIoUEval (nms_gpu.py:552-570): rbox1 = (q1, dims d1a x d1b), rbox2 likewise.
+// `disjoint`: the caller knows that the quads' bounding boxes are strictly apart -- then inter() finds no corner inside
+// the other quad and no edge crossing, i.e. returns exactly 0.0, and only the criterion's formula is left to evaluate
 template <class Pts = PrivatePts>
 __device__ __forceinline__ float iou_eval(const Quad &q1, float d1a, float d1b, const Quad &q2,
-                                          float d2a, float d2b, int criterion, Pts B = Pts()) {
+                                          float d2a, float d2b, int criterion, Pts B = Pts(), bool disjoint = false) {
   const float area1 = d1a * d1b, area2 = d2a * d2b;
-  const double ai = quad_inter_f32(q1, q2, B);
+  const double ai = disjoint ? 0.0 : quad_inter_f32(q1, q2, B);
   if (criterion == -1) return (float)(ai / ((double)(area1 + area2) - ai));
   if (criterion == 0) return (float)(ai / area1);
   if (criterion == 1) return (float)(ai / area2);
@@ -243,6 +245,7 @@ struct BoxRec {
   Quad q;
   float d0, d1, z0, z1;
   float raw[5];
+  float lo[2], hi[2];   // bounding box of the corners
 };
 __device__ __forceinline__ void load_box(const IouArgs &a, const float *base, int idx, bool is_row,
                                          BoxRec &r) {
@@ -262,6 +265,11 @@ __device__ __forceinline__ void load_box(const IouArgs &a, const float *base, in
   r.d0 = d0; r.d1 = d1;
   r.raw[0] = xc; r.raw[1] = yc; r.raw[2] = d0; r.raw[3] = d1; r.raw[4] = ang;
   r.q = make_quad(xc, yc, d0, d1, ang);
+#pragma unroll
+  for (int d = 0; d < 2; d++) {
+    r.lo[d] = fminf(fminf(r.q.p[d], r.q.p[2 + d]), fminf(r.q.p[4 + d], r.q.p[6 + d]));
+    r.hi[d] = fmaxf(fmaxf(r.q.p[d], r.q.p[2 + d]), fmaxf(r.q.p[4 + d], r.q.p[6 + d]));
+  }
 }
 
 __global__ __launch_bounds__(256) void k_iou_matrix(IouArgs a) {
@@ -282,8 +290,11 @@ __global__ __launch_bounds__(256) void k_iou_matrix(IouArgs a) {
     const int rr = rg * 16 + i;
     if (r0 + rr >= a.N) break;
     const BoxRec &rb = srow[rr];
-    // kernel order (nms_gpu.py:605-611): rbox1 = query (col), rbox2 = box (row)
-    float v = iou_eval(cb.q, cb.d0, cb.d1, rb.q, rb.d0, rb.d1, a.criterion);
+    // kernel order (nms_gpu.py:605-611): rbox1 = query (col), rbox2 = box (row).  Most pairs of an anchors x targets
+    // matrix are far apart: their bounding boxes do not touch and the intersection is exactly 0 (NaN corners compare
+    // false and take the full path)
+    const bool apart = cb.hi[0] < rb.lo[0] || rb.hi[0] < cb.lo[0] || cb.hi[1] < rb.lo[1] || rb.hi[1] < cb.lo[1];
+    float v = iou_eval(cb.q, cb.d0, cb.d1, rb.q, rb.d0, rb.d1, a.criterion, PrivatePts(), apart);
     bool same = true;  // check_same_boxes, nms_gpu.py:653-664
 #pragma unroll
     for (int d = 0; d < 5; d++) same = same && (fabsf(rb.raw[d] - cb.raw[d]) < (float)1e-6);
