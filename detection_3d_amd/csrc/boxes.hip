@@ -509,6 +509,8 @@ __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long *__re
     const int nrow = min(64, n - base);
     load_rows(c + 2, w_fill);
     const unsigned long long diag_next = load_diag(c + 1);
+    // (requested before the chain: read through `order`, it is a global load the survivors' store would wait for)
+    const int my_box = lane < nrow ? seg_box(g, sb, base + lane) : 0;
     // word c of the removed set, read into SGPRs: alive / kept / cnt and with them the whole chain stay scalar
     unsigned long long alive =
         ~(((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(removed >> 32), c) << 32) |
@@ -516,13 +518,23 @@ __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long *__re
     if (nrow < 64) alive &= (1ull << nrow) - 1ull;
     unsigned long long kept = 0;
     const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
-    for (int b = 0; b < nrow; b++) {
-      // b is wave-uniform: v_readlane instead of a ds_bpermute round trip per dependent step
-      const unsigned long long d = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
-                                   (unsigned int)__builtin_amdgcn_readlane((int)dlo, b);
-      if ((alive >> b) & 1ull) {
-        kept |= 1ull << b;
-        alive &= ~d;
+    // The dependent chain over the chunk's 64 boxes, a quarter of a chunk at a time: first the 16 diagonal words are moved
+    // into scalar registers (independent v_readlane pairs, they pipeline), then the chain itself is pure scalar ALU --
+    // test bit b of `alive`, clear the boxes that box b suppresses -- instead of two v_readlane round trips inside
+    // every dependent step.  Rows past the segment's end have a zero word and no `alive` bit.
+#pragma unroll
+    for (int part = 0; part < 4; part++) {
+      unsigned long long d[16];
+#pragma unroll
+      for (int b = 0; b < 16; b++)
+        d[b] = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, part * 16 + b) << 32) |
+               (unsigned int)__builtin_amdgcn_readlane((int)dlo, part * 16 + b);
+#pragma unroll
+      for (int b = 0; b < 16; b++) {
+        const unsigned long long bit = 1ull << (part * 16 + b);
+        const bool on = (alive & bit) != 0;
+        kept |= on ? bit : 0ull;
+        alive &= on ? ~d[b] : ~0ull;
       }
     }
 #pragma unroll
@@ -531,7 +543,7 @@ __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long *__re
     // survivors of the chunk, all lanes at once
     if ((kept >> lane) & 1ull) {
       const int pos = cnt + __popcll(kept & lt);
-      if (pos < g.n_max) keep[pos] = seg_box(g, sb, base + lane);
+      if (pos < g.n_max) keep[pos] = my_box;
     }
     cnt += __popcll(kept);
     diag = diag_next;
