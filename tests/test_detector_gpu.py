@@ -267,3 +267,23 @@ def test_post_select_against_numpy(dev, nseg, n_max, D):
     assert np.array_equal(out_l[:n].cpu().numpy(), want_l)
     if 0 < D < s.size and int((s >= 0).sum()) >= D:
         assert n >= D                                                 # ties on the threshold all stay
+
+
+@pytest.mark.parametrize("n_points", [40, 300, 2000])
+def test_tiny_scenes_pass_through_the_threaded_schedule(dev, n_points):
+    """A handful of points (coarse levels with a single site, rulebooks of one row, offset-split launches of one block)
+    through the default pass -- grid chain and rulebook views on the library's threads -- and back to a full-size
+    building on the same recycled metadata handles: finite detections, no hang."""
+    from detection_3d_amd.config import get_cfg
+    from detection_3d_amd.detector import build_detection_model
+    from detection_3d_amd.synthetic import make_scene
+    from detection_3d_amd.voxelize import voxelize
+    cfg = get_cfg("4c_Fpn432")
+    torch.manual_seed(0)
+    model = build_detection_model(cfg).to(dev).eval()
+    with torch.no_grad():
+        for n in (n_points, 60000, n_points):
+            pcl = torch.from_numpy(make_scene(3, n)).to(dev)
+            r = model(list(voxelize(pcl, 50, cfg.SPARSE3D.VOXEL_FULL_SCALE)))
+            assert r["bbox3d"].shape[1] == 7 and torch.isfinite(r["bbox3d"]).all() and torch.isfinite(r["scores"]).all()
+            assert r["labels"].shape[0] == r["scores"].shape[0] == r["bbox3d"].shape[0] <= cfg.MODEL.ROI_HEADS.DETECTIONS_PER_IMG * 4
