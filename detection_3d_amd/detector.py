@@ -21,6 +21,7 @@ from torch import nn
 
 from . import box_ops
 from ._lib import check, lib, ptr, stream_of
+from ._lib import ints as _ints
 from . import sparseconvnet as scn
 from . import training as T
 from .config import class_to_label
@@ -130,12 +131,17 @@ class AnchorGenerator(nn.Module):
         ns = [f.features.shape[0] for f in feature_maps_sparse]
         out = torch.empty((sum(ns) * A, 7), dtype=torch.float32, device=feature_maps_sparse[0].features.device)
         o = 0
-        lists = getattr(self, "_anchor_lists", None)
-        if lists is None:       # host copies of the (constant) cell anchors and strides, made once
-            lists = self._anchor_lists = [(b.tolist(), st.tolist()) for b, st in zip(self.cell_anchors, self.strides)]
-        for (base, stride), fmap, n in zip(lists, feature_maps_sparse, ns):
+        consts = getattr(self, "_anchor_consts", None)
+        if consts is None:      # host copies of the (constant) cell anchors and strides as C arrays, made once
+            from ._lib import floats
+            consts = self._anchor_consts = [(floats([float(v) for row in b.tolist() for v in row]), b.shape[0],
+                                             floats([float(v) for v in st.tolist()]))
+                                            for b, st in zip(self.cell_anchors, self.strides)]
+        stream = stream_of()
+        for (base, n_base, stride), fmap, n in zip(consts, feature_maps_sparse, ns):
             if n:
-                fmap.metadata.anchors(fmap.spatial_size, base, stride, self.voxel_scale, out[o * A:(o + n) * A])
+                check(lib().d3d_anchors(fmap.metadata._h, _ints(scn.SCN._size3(fmap.spatial_size)), base, n_base,
+                                        stride, float(self.voxel_scale), ptr(out[o * A:(o + n) * A]), stream))
             o += n
         return out
 
