@@ -1,0 +1,143 @@
+// a12. RPN head at inference (modeling/rpn/rpn_sparse3d.py:80-131, SingleConvRPNHead_Sparse3D): the three 1x1
+// convolutions over the active sites of the selected maps -- t = relu(x W1^T + b1), objectness = t Wc^T + bc,
+// regression = t Wr^T + br -- as ONE launch over the maps' rows where they lie (no concatenation, t never leaves the
+// CU): three library GEMMs + a concatenation + an activation cost the launch thread 0.3 ms per building, more than the
+// 0.6 GFLOP take on the matrix cores.
+//
+// A workgroup owns 32 site rows (the row space is the maps' rows laid end to end, which is the flattening order of
+// cat_scales_obj_reg, rpn_sparse3d.py:19-77: scale, site, anchor) and C/32 waves.  Stage 1: wave w holds the 32x32
+// accumulator of columns 32w.. of t (v_mfma_f32_32x32x2_f32 over Cin, A from the LDS tile of the rows, B from the
+// k-interleaved packed weights as in k_conv); bias + ReLU; t replaces the rows in LDS.  Stage 2: the a objectness and
+// 7a regression columns are one packed [C, 8a] operand (32 columns for a = 4), a 32-column tile per wave.
+#include "d3d_internal.h"
+
+namespace d3d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct RpnMaps {
+  const float *p[D3D_RPN_MAX_MAPS];
+  int start[D3D_RPN_MAX_MAPS + 1];  // first row of map m in the row space; start[n_maps] = all rows
+  int n_maps;
+};
+
+// wp = packed[g][co][j] = W[co][4g + j] (W in nn.Linear layout [cout, cin]); one 32-column tile at column `colbase`
+template <int C>
+__device__ __forceinline__ f32x16 tile_product(const float *__restrict__ As, int lda, const float *__restrict__ wp,
+                                               int cout, int colbase, int r, int h) {
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = 0.f;
+  const float *wl = wp + ((size_t)h * cout + colbase + r) * 4;
+#pragma unroll 4
+  for (int q = 0; q < C / 8; q++) {
+    const f32x4 a = *(const f32x4 *)(As + r * lda + q * 8 + h * 4);
+    const f32x4 b = *(const f32x4 *)(wl + (size_t)(2 * q) * cout * 4);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+template <int C>
+__global__ __launch_bounds__(C / 32 * 64) void k_rpn_head(RpnMaps maps, const float *__restrict__ w1p,
+                                                          const float *__restrict__ b1, const float *__restrict__ w2p,
+                                                          const float *__restrict__ b2, int a, int out_tiles,
+                                                          float *__restrict__ obj, float *__restrict__ reg) {
+  constexpr int W = C / 32, LDA = C + 4, LPR = C / 4;
+  __shared__ __attribute__((aligned(16))) float As[32 * LDA];
+  const int n = maps.start[maps.n_maps];
+  const int row0 = blockIdx.x * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6, r = lane & 31, h = lane >> 5;
+
+  for (int i = tid; i < 32 * LPR; i += W * 64) {
+    const int row = i / LPR, c4 = i % LPR, g = row0 + row;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (g < n) {
+      int m = 0;
+      while (m + 1 < maps.n_maps && g >= maps.start[m + 1]) m++;
+      v = *(const f32x4 *)(maps.p[m] + (size_t)(g - maps.start[m]) * C + c4 * 4);
+    }
+    *(f32x4 *)(As + row * LDA + c4 * 4) = v;
+  }
+  __syncthreads();
+  // C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  {
+    const f32x16 acc = tile_product<C>(As, LDA, w1p, C, wib * 32, r, h);
+    const int col = wib * 32 + r;
+    const float bias = b1[col];
+    __syncthreads();  // every wave has read the rows
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+      const float v = acc[i] + bias;
+      As[row * LDA + col] = v < 0.f ? 0.f : v;   // relu; a NaN stays a NaN
+    }
+  }
+  __syncthreads();
+  const int nout = out_tiles * 32;
+  for (int t = wib; t < out_tiles; t += W) {
+    const f32x16 acc = tile_product<C>(As, LDA, w2p, nout, t * 32, r, h);
+    const int col = t * 32 + r;
+    if (col >= 8 * a) continue;
+    const float bias = b2[col];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+      const size_t g = (size_t)row0 + row;
+      if (g >= (size_t)n) continue;
+      const float v = acc[i] + bias;
+      if (col < a)
+        obj[g * a + col] = v;
+      else
+        reg[g * (7 * a) + (col - a)] = v;
+    }
+  }
+}
+
+}  // namespace d3d
+
+using namespace d3d;
+
+extern "C" {
+
+int d3d_rpn_head(const float *const *maps_host, const int *rows_host, int n_maps, int channels, const float *w1_packed,
+                 const float *b1, const float *w2_packed, const float *b2, int a, float *objectness, float *regression,
+                 void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(maps_host && rows_host && n_maps >= 1 && n_maps <= D3D_RPN_MAX_MAPS, "rpn_head: 1..%d maps",
+              D3D_RPN_MAX_MAPS);
+  D3D_REQUIRE(channels == 128 || channels == 256, "rpn_head: %d channels (built for 128 and 256)", channels);
+  D3D_REQUIRE(a >= 1 && w1_packed && b1 && w2_packed && b2 && objectness && regression, "rpn_head: bad arguments");
+  RpnMaps maps;
+  long n = 0;
+  for (int m = 0; m < D3D_RPN_MAX_MAPS; m++) {
+    maps.p[m] = nullptr;
+    maps.start[m] = (int)n;
+    if (m < n_maps) {
+      D3D_REQUIRE(rows_host[m] >= 0 && (rows_host[m] == 0 || maps_host[m]), "rpn_head: map %d", m);
+      maps.p[m] = maps_host[m];
+      n += rows_host[m];
+    }
+  }
+  D3D_REQUIRE(n * 7L * a < (1L << 31), "rpn_head: %ld rows", n);
+  maps.start[D3D_RPN_MAX_MAPS] = (int)n;
+  for (int m = n_maps; m <= D3D_RPN_MAX_MAPS; m++) maps.start[m] = (int)n;
+  maps.n_maps = n_maps;
+  if (n == 0) return D3D_OK;
+  const int out_tiles = (8 * a + 31) / 32;
+  const dim3 grid((unsigned)((n + 31) / 32));
+  if (channels == 128)
+    hipLaunchKernelGGL(k_rpn_head<128>, grid, dim3(256), 0, s, maps, w1_packed, b1, w2_packed, b2, a, out_tiles,
+                       objectness, regression);
+  else
+    hipLaunchKernelGGL(k_rpn_head<256>, grid, dim3(512), 0, s, maps, w1_packed, b1, w2_packed, b2, a, out_tiles,
+                       objectness, regression);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+}  // extern "C"

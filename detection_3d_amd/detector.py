@@ -179,9 +179,53 @@ class RPNHead(nn.Module):
     def _lin(layer, x):
         return F.linear(x, layer.weight.view(layer.weight.shape[0], -1), layer.bias)
 
+    def _fused_ok(self, features):
+        c = self.conv.weight.shape[0]
+        return (c in (128, 256) and 1 <= len(features) <= 6 and
+                all(f.is_cuda and f.dtype == torch.float32 and f.is_contiguous() and f.dim() == 2 and f.shape[1] == c
+                    for f in features))
+
+    def _packed(self):
+        """The operands of d3d_rpn_head: W[co][4g+j] -> [g][co][j]; objectness and regression weights stacked into one
+        [8a, C] operand padded to whole 32-column tiles.  Re-made when a parameter changes (in-place updates bump
+        `_version`, loads and `.to()` replace the storage)."""
+        ps = (self.conv.weight, self.conv.bias, self.cls_logits.weight, self.cls_logits.bias,
+              self.bbox_pred.weight, self.bbox_pred.bias)
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_pack", (None,))[0] != key:
+            c = self.conv.weight.shape[0]
+
+            def pack(w):                                    # [cout, c] -> [c/4, cout, 4]
+                return w.view(w.shape[0], c // 4, 4).permute(1, 0, 2).contiguous()
+
+            w2 = torch.cat([self.cls_logits.weight.detach().view(-1, c), self.bbox_pred.weight.detach().view(-1, c)], 0)
+            pad = (-w2.shape[0]) % 32
+            if pad:
+                w2 = torch.cat([w2, w2.new_zeros(pad, c)], 0)
+            self._pack = (key, pack(self.conv.weight.detach().view(c, c)), self.conv.bias.detach().contiguous(),
+                          pack(w2), torch.cat([self.cls_logits.bias.detach(), self.bbox_pred.bias.detach()]).contiguous())
+        return self._pack[1:]
+
+    def _forward_fused(self, features):
+        """One d3d_rpn_head launch over the maps' rows where they lie (no concatenation, no library GEMMs)."""
+        import ctypes
+        w1, b1, w2, b2 = self._packed()
+        a = self.num_anchors_per_location * self.seperate_rpn
+        n = sum(f.shape[0] for f in features)
+        dev = features[0].device
+        obj = torch.empty((n, a), dtype=torch.float32, device=dev)
+        reg = torch.empty((n, 7 * a), dtype=torch.float32, device=dev)
+        maps = (ctypes.c_void_p * len(features))(*[f.data_ptr() for f in features])
+        check(lib().d3d_rpn_head(maps, _ints(tuple(int(f.shape[0]) for f in features)), len(features),
+                                 int(features[0].shape[1]), ptr(w1), ptr(b1), ptr(w2), ptr(b2), a, ptr(obj), ptr(reg),
+                                 stream_of()))
+        return obj.view(-1, self.seperate_rpn), reg.view(-1, 7 * self.seperate_rpn)
+
     def forward(self, features):
         """features: list of [n_s, C]  ->  objectness [sum n_s*A], regression [sum n_s*A, 7] in the
         flattening order of cat_scales_obj_reg (:19-77): scale, site, anchor."""
+        if not torch.is_grad_enabled() and self._fused_ok(features):
+            return self._forward_fused(features)
         if not torch.is_grad_enabled() and len(features) > 1:
             # the head is shared by the scales and acts per site: one GEMM over the concatenated sites
             t = F.relu(self._lin(self.conv, torch.cat(features, 0)))

@@ -125,6 +125,19 @@ int d3d_get_spatial_locations(d3d_meta *m, const int *spatial_size_host, int64_t
 int d3d_anchors(d3d_meta *m, const int *spatial_size_host, const float *base_host, int A,
                 const float *stride_host, float voxel_scale, float *out, void *stream);
 
+/* a12. RPN head at inference, SingleConvRPNHead_Sparse3D.forward + cat_scales_obj_reg
+ * (modeling/rpn/rpn_sparse3d.py:80-131 and :19-77) for all selected maps in ONE launch:
+ *   t = relu(x W1^T + b1);  objectness = t Wc^T + bc  [n, a];  regression = t Wr^T + br  [n, 7a]
+ * over the n = sum(rows_host) site rows of the maps laid end to end (scale, site, anchor order).
+ * maps_host[m]: device pointer of map m's features [rows_host[m], channels] fp32 (channels 128 or 256);
+ * w1_packed [channels/4, channels, 4] with w1_packed[g][co][j] = W1[co][4g+j] (W1 = conv.weight [channels, channels]);
+ * w2_packed [channels/4, NOUT, 4] likewise for the rows of (Wc; Wr) = [8a, channels] zero-padded to
+ * NOUT = 32*ceil(8a/32) columns; b1 [channels], b2 [8a] = (bc; br).  a = anchors per site x class groups.          */
+#define D3D_RPN_MAX_MAPS 6
+int d3d_rpn_head(const float *const *maps_host, const int *rows_host, int n_maps, int channels,
+                 const float *w1_packed, const float *b1, const float *w2_packed, const float *b2, int a,
+                 float *objectness, float *regression, void *stream);
+
 /* a4. Metadata::getSubmanifoldRuleBook (Metadata.cpp:430-443; SubmanifoldConvolutionRules.h:27-45).
  * Builds (or finds cached) the rulebook; *n_rules_host = number of (in,out) pairs.           */
 int d3d_subm_prepare(d3d_meta *m, const int *spatial_size_host, const int *filter_host,
