@@ -13,6 +13,7 @@ objects; fields travel next to them in a small dict.  SEPARATE_CLASSES (3G6c) ru
 and the RoI losses / post-processing once per class group (SeperateClassifier).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -98,6 +99,9 @@ def build_backbone(cfg):
                        bn_momentum=cfg.SOLVER.BN_MOMENTUM, track_running_stats=cfg.SOLVER.TRACK_RUNNING_STATS)
 
 
+_FUSED_RPN_HEAD = os.environ.get("D3D_RPN_HEAD", "fused") != "gemm"     # "gemm": the library-GEMM form, for A/B runs
+
+
 # ----------------------------------------------------------------------------------------------
 class AnchorGenerator(nn.Module):
     """modeling/rpn/anchor_generator_sparse3d.py:44-120,207-241: one anchor size per selected map,
@@ -181,7 +185,7 @@ class RPNHead(nn.Module):
 
     def _fused_ok(self, features):
         c = self.conv.weight.shape[0]
-        return (c in (128, 256) and 1 <= len(features) <= 6 and
+        return (_FUSED_RPN_HEAD and c in (128, 256) and 1 <= len(features) <= 6 and
                 all(f.is_cuda and f.dtype == torch.float32 and f.is_contiguous() and f.dim() == 2 and f.shape[1] == c
                     for f in features))
 
