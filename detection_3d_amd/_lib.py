@@ -47,6 +47,8 @@ _SIGS = {
                                        vp]),
     "d3d_roi_prepare": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_float, c_float_p, ctypes.c_int, ctypes.c_float, vp, vp,
                                        vp, vp]),
+    "d3d_roi_prepare_counted": (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.c_float, c_float_p, ctypes.c_int,
+                                               ctypes.c_float, vp, vp, vp, vp]),
     "d3d_voxelize": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_int_p, vp, vp,
                                     c_int_p, vp, ctypes.c_size_t, vp]),
     "d3d_voxelize_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int]),

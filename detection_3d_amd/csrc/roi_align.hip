@@ -385,9 +385,17 @@ struct RoiPrepScales {
 __global__ __launch_bounds__(256) void k_roi_prepare(const float *__restrict__ boxes, int n, float voxel_scale,
                                                      RoiPrepScales scales, int n_levels, float inv_canonical,
                                                      float *__restrict__ rois, int32_t *__restrict__ levels,
-                                                     const int32_t *__restrict__ batch_ids) {
+                                                     const int32_t *__restrict__ batch_ids,
+                                                     const int32_t *__restrict__ count) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (count && i >= *count) {   // padding row of a list whose length is still on the device: no level pools it
+    float *r = rois + (size_t)i * 8;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = 0.f;
+    if (levels) levels[i] = -1;
+    return;
+  }
   float b[7];
 #pragma unroll
   for (int j = 0; j < 7; j++) b[j] = boxes[(size_t)i * 7 + j];
@@ -425,6 +433,13 @@ extern "C" {
 
 int d3d_roi_prepare(const float *boxes_metric, int n, float voxel_scale, const float *scales_host, int n_levels,
                     float canonical_size, const int32_t *batch_ids, float *rois, int32_t *levels, void *stream) {
+  return d3d_roi_prepare_counted(boxes_metric, n, nullptr, voxel_scale, scales_host, n_levels, canonical_size, batch_ids,
+                                 rois, levels, stream);
+}
+
+int d3d_roi_prepare_counted(const float *boxes_metric, int n, const int32_t *count_dev, float voxel_scale,
+                            const float *scales_host, int n_levels, float canonical_size, const int32_t *batch_ids,
+                            float *rois, int32_t *levels, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   D3D_REQUIRE(n >= 0 && n_levels >= 0 && n_levels <= 8, "roi_prepare: bad arguments (at most 8 levels)");
   if (n == 0) return D3D_OK;
@@ -432,7 +447,7 @@ int d3d_roi_prepare(const float *boxes_metric, int n, float voxel_scale, const f
   RoiPrepScales sc = {};
   for (int l = 0; l < n_levels; l++) sc.v[l] = scales_host[l];
   hipLaunchKernelGGL(k_roi_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, boxes_metric, n, voxel_scale, sc,
-                     n_levels, 1.f / canonical_size, rois, n_levels > 1 ? levels : nullptr, batch_ids);
+                     n_levels, 1.f / canonical_size, rois, n_levels > 1 ? levels : nullptr, batch_ids, count_dev);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }

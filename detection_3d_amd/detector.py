@@ -243,6 +243,49 @@ class RPNHead(nn.Module):
         return torch.cat(obj, 0), torch.cat(reg, 0)
 
 
+class PaddedProposals(object):
+    """The RPN's proposals of one example before the survivor count of its NMS is read back: `boxes` [P, 7] and `scores`
+    [P] padded to P = FPN_POST_NMS_TOP_N rows, `count` int32 [1] on the device = the real rows (the first ones)."""
+
+    _lanes = {}     # (device, caller's stream) -> (copy stream, pinned word, event "count written", event "count copied")
+
+    def __init__(self, boxes, scores, count, readback=None):
+        self.boxes, self.scores, self.count, self._readback = boxes, scores, count, readback
+
+    @classmethod
+    def start_readback(cls, count):
+        """Copies `count` (just enqueued on the caller's stream) to a pinned word on a side stream, so that the host
+        can wait for it alone -- not for the pooler launches that follow it on the caller's stream."""
+        from ._lib import raw_stream
+        dev = count.device
+        key = (dev.index, raw_stream(dev))
+        lane = cls._lanes.get(key)
+        if lane is None:
+            lane = cls._lanes[key] = (torch.cuda.Stream(device=dev, priority=-1),
+                                      torch.empty(1, dtype=torch.int32).pin_memory(),
+                                      torch.cuda.Event(), torch.cuda.Event())
+        side, word, written, copied = lane
+        written.record()
+        side.wait_event(written)
+        with torch.cuda.stream(side):
+            word.copy_(count, non_blocking=True)
+            copied.record()
+        return word, copied
+
+    def resolve(self):
+        """the one host synchronisation -> (boxes [n, 7], scores [n])"""
+        if self._readback is not None:
+            word, copied = self._readback
+            copied.synchronize()
+            n = int(word[0])
+        else:
+            n = int(self.count.item())
+        return self.boxes[:n], self.scores[:n]
+
+
+_DEFER_PROPOSALS = os.environ.get("D3D_DEFER_PROPOSALS", "1") != "0"
+
+
 class RPNModule(nn.Module):
     """modeling/rpn/rpn_sparse3d.py:137-231 + rpn/inference_3d.py:82-163 (test path)."""
 
@@ -260,12 +303,19 @@ class RPNModule(nn.Module):
         self.sep = SeperateClassifier(cfg.MODEL.SEPARATE_CLASSES_ID, len(cfg.INPUT.CLASSES))
 
     @torch.no_grad()
-    def select_proposals(self, objectness, box_regression, anchors, train):
+    def select_proposals(self, objectness, box_regression, anchors, train, defer=False):
+        """defer (inference): -> PaddedProposals -- the survivors gathered into `post` rows with their count left on the
+        device, so that the pooler is enqueued behind the NMS without waiting for its read-back."""
         pre, post = self.top_n[bool(train)]
         scores = objectness.reshape(-1).sigmoid()
         k = min(pre, scores.shape[0])
         scores_k, idx = scores.topk(k, dim=0, sorted=True)                      # inference_3d.py:109
         proposals = box_ops.box_decode(box_regression[idx], anchors[idx])       # :123
+        if defer and 0 < k <= 2000 and post > 100:
+            keep, nk = box_ops.nms_3d_batched(proposals, None, None, k, self.nms_thresh, self.nms_aug_thickness, post)
+            readback = PaddedProposals.start_readback(nk)
+            rows = keep[0, :min(post, k)].long().clamp_(0, k - 1)               # past the count: any valid row
+            return PaddedProposals(proposals[rows], scores_k[rows], nk, readback)
         keep = box_ops.nms_3d_presorted(proposals, self.nms_thresh, self.nms_aug_thickness, max_proposals=post,
                                         flag='rpn_post')                        # scores_k is sorted: no re-sort
         return proposals[keep], scores_k[keep]
@@ -306,8 +356,9 @@ class RPNModule(nn.Module):
             out.append((props[sel], sk[sel]))
         return out
 
-    def forward(self, features_sparse, targets=None, n_examples=1):
-        """eval: (proposals, objectness).  train: (proposals incl. GT boxes, objectness, loss dict)
+    def forward(self, features_sparse, targets=None, n_examples=1, defer=False):
+        """eval: (proposals, objectness) -- or, with defer, a PaddedProposals when the path allows it.
+        train: (proposals incl. GT boxes, objectness, loss dict)
         (rpn_sparse3d.py:233-270, rpn/inference_3d.py:53-80,180-199).  n_examples > 1 (inference): returns
         (proposals, objectness, sep_id or None, example_id) with the rows ordered by example (then class group)."""
         objectness, box_regression = self.head([f.features for f in features_sparse])
@@ -331,10 +382,11 @@ class RPNModule(nn.Module):
             return (torch.cat([p for p, _ in segs]), torch.cat([sc for _, sc in segs]), sep_id if grouped else None, ex_id)
         if grouped:
             return self._forward_grouped(anchors, objectness, box_regression, targets)
-        proposals, scores = self.select_proposals(objectness.detach(), box_regression.detach(), anchors,
-                                                  self.training)
+        out = self.select_proposals(objectness.detach(), box_regression.detach(), anchors, self.training,
+                                    defer=defer and not self.training and _DEFER_PROPOSALS)
         if not self.training:
-            return proposals, scores
+            return out
+        proposals, scores = out
         gt = targets["bbox3d"]
         if self.add_gt_proposals and gt.shape[0]:
             proposals = torch.cat([proposals, gt], 0)
@@ -396,12 +448,12 @@ class Pooler(nn.Module):
         dif = torch.abs(torch.tensor(self.scales, device=boxes.device)[None, :] - rate[:, None])
         return torch.argmin(dif, 1)
 
-    def pool_metric(self, x, boxes_metric, voxel_scale, channels_inner=True, batch_ids=None):
+    def pool_metric(self, x, boxes_metric, voxel_scale, channels_inner=True, batch_ids=None, count=None):
         """Inference: metric proposals -> pooled features with ONE pre-processing launch (pixels, RoI format and FPN
         level: d3d_roi_prepare, bit-identical to convert_to_roi_format / map_levels) and one launch per level that
         fills its RoIs' slots of the result in place (no nonzero / index_put, no host synchronisation)."""
         ph, pw, pz = self.output_size
-        rois, levels = roi_prepare(boxes_metric, voxel_scale, self.scales, self.canonical_size, batch_ids)
+        rois, levels = roi_prepare(boxes_metric, voxel_scale, self.scales, self.canonical_size, batch_ids, count)
         K, C = rois.shape[0], x[0].features.shape[1]
         out = torch.empty((K, ph, pw, C, pz) if channels_inner else (K, C, ph, pw, pz), dtype=torch.float32,
                           device=rois.device)
@@ -481,12 +533,31 @@ class FPN2MLPFeatureExtractor(nn.Module):
                               .contiguous())
         return self._fc6_rows[1]
 
-    def _forward_rows(self, x0, p, batch_ids=None):
+    def rows_path_ok(self, padded=False):
+        """whether `_forward_rows` serves this configuration (padded: with the proposal count still on the device, which
+        needs the level map of a multi-level pooler to switch the padding rows off)"""
+        conv, bn = self.conv3d[0], self.conv3d[1]
+        return (not torch.is_grad_enabled() and tuple(conv.kernel_size) == (1, 1, self.pooler.output_size[2])
+                and tuple(conv.stride) == (1, 1, 1) and (bn.training or not bn.track_running_stats)
+                and (not padded or len(self.pooler.scales) > 1))
+
+    def forward_padded(self, x0, padded):
+        """PaddedProposals (sizes already clamped) -> (box features [n, rep], proposals [n, 7], scores [n]): the pooler is
+        enqueued over all padded rows, then the count is read back and the head runs over the real ones."""
+        pooled = self.pooler.pool_metric(x0, padded.boxes, self.voxel_scale, channels_inner=True, count=padded.count)
+        proposals, scores = padded.resolve()
+        n = proposals.shape[0]
+        if n == 0:
+            return self.forward(x0, proposals), proposals, scores
+        return self._forward_rows(x0, proposals, pooled=pooled[:n]), proposals, scores
+
+    def _forward_rows(self, x0, p, batch_ids=None, pooled=None):
         """Inference path without layout changes (p: metric proposals): the pooler writes [K, ph, pw, C, pz], whose rows feed the
         [1,1,pz] convolution as a GEMM; BatchNorm3d + ReLU is one row-wise BatchNorm over [K*ph*pw, rep]
         (batch statistics, biased variance: F.batch_norm in training mode), fc6 reads the rows in place."""
         conv, bn = self.conv3d[0], self.conv3d[1]
-        pooled = self.pooler.pool_metric(x0, p, self.voxel_scale, channels_inner=True, batch_ids=batch_ids)
+        if pooled is None:
+            pooled = self.pooler.pool_metric(x0, p, self.voxel_scale, channels_inner=True, batch_ids=batch_ids)
         mark("rois pooled")
         K, ph, pw, C, pz = pooled.shape
         y = torch.addmm(conv.bias, pooled.view(K * ph * pw, C * pz), conv.weight.view(conv.out_channels, C * pz).t())
@@ -502,10 +573,7 @@ class FPN2MLPFeatureExtractor(nn.Module):
     def forward(self, x0, proposals, batch_ids=None):
         """batch_ids: int32 [K] example of every proposal (inference with several examples per batch; the RoI op reads
         the example's sites, poolers_3d.py:112-118); None = one example."""
-        conv, bn = self.conv3d[0], self.conv3d[1]
-        if (not torch.is_grad_enabled() and tuple(conv.kernel_size) == (1, 1, self.pooler.output_size[2])
-                and tuple(conv.stride) == (1, 1, 1) and (bn.training or not bn.track_running_stats)
-                and proposals.shape[0] > 0):
+        if self.rows_path_ok() and proposals.shape[0] > 0:
             return self._forward_rows(x0, proposals, batch_ids)                 # metric boxes: pixels on the device
         if batch_ids is not None:
             raise NotImplementedError("several examples per batch: only the inference path of the box head is built")
@@ -754,6 +822,12 @@ class ROIBoxHead3D(nn.Module):
             results.append({k: torch.cat([r[k] for r in parts]) for k in ("bbox3d", "scores", "labels")})
         return results
 
+    def forward_padded(self, roi_features, padded):
+        """inference from a PaddedProposals -> (detections dict, proposals [n, 7], scores [n])"""
+        x, proposals, scores = self.feature_extractor.forward_padded(roi_features, padded)
+        logits, reg = self.predictor(x)
+        return self.post_processor(logits, reg, proposals), proposals, scores
+
     def forward(self, roi_features, proposals, targets=None, sep_id=None, example_id=None, n_examples=1):
         if n_examples > 1:
             assert not self.training
@@ -834,8 +908,18 @@ class SparseRCNN(nn.Module):
         after the other as the reference's collate does) a list of such dicts, one per example."""
         rpn_features, roi_features = features
         mark("backbone done")
-        out = self.rpn(rpn_features, n_examples=n_examples)
+        out = self.rpn(rpn_features, n_examples=n_examples,
+                       defer=self.roi_heads.box.feature_extractor.rows_path_ok(padded=True))
         mark("proposals")
+        if isinstance(out, PaddedProposals):
+            # the pooler goes out behind the NMS; the survivor count is read back while it runs
+            out.boxes[:, 3:6] = torch.clamp(out.boxes[:, 3:6], min=0.001)       # BoxList3D.clamp_size
+            result, proposals, objectness = self.roi_heads.box.forward_padded(roi_features, out)
+            mark("detections")
+            if return_intermediates:
+                return result, {"rpn_features": rpn_features, "roi_features": roi_features,
+                                "proposals": proposals, "objectness": objectness, "example_id": None}
+            return result
         proposals, objectness = out[0].clone(), out[1]
         example_id = None
         if n_examples > 1:

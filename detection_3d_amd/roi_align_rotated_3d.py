@@ -117,10 +117,12 @@ def roi_align_rotated_3d_sparse_into(out, feat_s3d, rois, spatial_scale, samplin
     return out
 
 
-def roi_prepare(boxes_metric, voxel_scale, scales, canonical_size, batch_ids=None):
+def roi_prepare(boxes_metric, voxel_scale, scales, canonical_size, batch_ids=None, count=None):
     """d3d_roi_prepare: metric yx_zb proposals [K,7] -> (rois [K,8] in pixels, levels int32 [K] or None for a single
     level) in one launch; equals convert_metric_to_pixel + convert_to_roi_format + Pooler.map_levels bit for bit.
-    batch_ids: int32 [K] example index of every proposal (None: one example)."""
+    batch_ids: int32 [K] example index of every proposal (None: one example).
+    count: int32 [1] on the device = how many of the K rows are real (d3d_roi_prepare_counted: the others get level -1
+    and are pooled by no level); needs more than one level."""
     b = boxes_metric.detach().to(torch.float32).contiguous()
     require_gpu(b)
     K = b.shape[0]
@@ -128,6 +130,11 @@ def roi_prepare(boxes_metric, voxel_scale, scales, canonical_size, batch_ids=Non
         assert batch_ids.dtype == torch.int32 and batch_ids.is_contiguous() and batch_ids.shape[0] == K
     rois = torch.empty((K, 8), dtype=torch.float32, device=b.device)
     levels = torch.empty((K,), dtype=torch.int32, device=b.device) if len(scales) > 1 else None
+    if count is not None:
+        assert count.dtype == torch.int32 and count.is_cuda and levels is not None
+        check(lib().d3d_roi_prepare_counted(ptr(b), K, ptr(count), float(voxel_scale), floats(scales), len(scales),
+                                            float(canonical_size), ptr(batch_ids), ptr(rois), ptr(levels), stream_of()))
+        return rois, levels
     check(lib().d3d_roi_prepare(ptr(b), K, float(voxel_scale), floats(scales), len(scales), float(canonical_size),
                                 ptr(batch_ids), ptr(rois), ptr(levels), stream_of()))
     return rois, levels

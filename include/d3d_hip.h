@@ -331,6 +331,12 @@ int d3d_sparse_to_dense_forward(d3d_meta *m, const int *spatial_size_host, const
  * batch_ids [n] (device, may be NULL = example 0): the example each box belongs to (poolers_3d.py:112-118).      */
 int d3d_roi_prepare(const float *boxes_metric, int n, float voxel_scale, const float *scales_host, int n_levels,
                     float canonical_size, const int32_t *batch_ids, float *rois, int32_t *levels, void *stream);
+/* ... for a proposal list padded to n rows whose real length *count_dev (<= n) is still on the device (the survivor
+ * count of the RPN's NMS, rpn/inference_3d.py:127-131, not yet read back): rows >= *count_dev get zero RoIs and level
+ * -1, so no level's RoIAlign launch pools them.  count_dev NULL: all n rows are real (= d3d_roi_prepare).          */
+int d3d_roi_prepare_counted(const float *boxes_metric, int n, const int32_t *count_dev, float voxel_scale,
+                            const float *scales_host, int n_levels, float canonical_size, const int32_t *batch_ids,
+                            float *rois, int32_t *levels, void *stream);
 /* a21. _C.roi_align_rotated_3d_forward (maskrcnn_benchmark/csrc/ROIAlignRotated3D.h:10-26;
  * csrc/cuda/ROIAlignRotated3D_cuda.cu:89-177).  Dense input [B,C,H,W,Z]; rois [K,8].          */
 int d3d_roi_align_rotated_3d_forward(const float *input, int B, int C, int H, int W, int Z,

@@ -324,3 +324,40 @@ def test_rpn_head_one_launch(dev, config, rows):
             obj_l, reg_l = head(feats)
         assert torch.allclose(obj, obj_l.detach(), rtol=1e-4, atol=1e-5 * float(wo.abs().max()))
         assert torch.allclose(reg, reg_l.detach(), rtol=1e-4, atol=1e-5 * float(wr.abs().max()))
+
+
+def test_deferred_proposal_count_matches_the_read_back_path(setup, dev, monkeypatch):
+    """The inference tail with the RPN's survivor count left on the device while the pooler is enqueued
+    (PaddedProposals, d3d_roi_prepare_counted) against the path that reads the count back first: proposals, their
+    scores and the detections are identical to the bit; the padding rows are switched off (level -1, zero RoIs)."""
+    from detection_3d_amd import detector
+    from detection_3d_amd.roi_align_rotated_3d import roi_prepare
+    from detection_3d_amd.synthetic import make_scene
+    from detection_3d_amd.voxelize import voxelize
+    cfg, model = setup[0], setup[1]
+    pcl = torch.from_numpy(make_scene(33, 45000)).to(dev)
+    got = {}
+    for defer in (True, False):
+        monkeypatch.setattr(detector, "_DEFER_PROPOSALS", defer)
+        c, f = voxelize(pcl, cfg.SPARSE3D.VOXEL_SCALE, cfg.SPARSE3D.VOXEL_FULL_SCALE)
+        seen = []
+        orig = detector.ROIBoxHead3D.forward_padded
+        monkeypatch.setattr(detector.ROIBoxHead3D, "forward_padded",
+                            lambda self, *a, _o=orig, **k: (seen.append(1), _o(self, *a, **k))[1])
+        res, mid = model([c, f], return_intermediates=True)
+        monkeypatch.setattr(detector.ROIBoxHead3D, "forward_padded", orig)
+        assert bool(seen) == defer                              # the deferred path is the one that ran (or not)
+        got[defer] = [res["bbox3d"], res["scores"], res["labels"], mid["proposals"], mid["objectness"]]
+    assert got[True][3].shape[0] > 0
+    for a, b in zip(got[True], got[False]):
+        assert a.shape == b.shape and torch.equal(a, b)
+    # d3d_roi_prepare_counted: real rows as d3d_roi_prepare, the others level -1 and zero RoIs
+    head = model.roi_heads.box.feature_extractor
+    boxes = got[True][3][:50].contiguous()
+    pad = torch.cat([boxes, boxes[:14]], 0)
+    for n in (50, 17, 0):
+        cnt = torch.tensor([n], dtype=torch.int32, device=dev)
+        rois, levels = roi_prepare(pad, head.voxel_scale, head.pooler.scales, head.pooler.canonical_size, None, cnt)
+        r0, l0 = roi_prepare(pad, head.voxel_scale, head.pooler.scales, head.pooler.canonical_size)
+        assert torch.equal(rois[:n], r0[:n]) and torch.equal(levels[:n], l0[:n])
+        assert bool((levels[n:] == -1).all()) and bool((rois[n:] == 0).all())
