@@ -936,4 +936,6 @@ class SparseRCNN(nn.Module):
 
 
 def build_detection_model(cfg):
+    from . import tuned_gemm
+    tuned_gemm.enable()         # library GEMMs of the tail: solutions picked ahead of time (no tuning at run time)
     return SparseRCNN(cfg)
