@@ -114,6 +114,10 @@ _SIGS = {
                                                                ctypes.c_int, ctypes.c_float, ctypes.c_int,
                                                                ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                                vp, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "d3d_roi_align_rotated_3d_sparse_forward_levels": (ctypes.c_int, [vp, ctypes.c_int, c_int_p, ctypes.POINTER(vp),
+                                                                      ctypes.c_int, c_float_p, vp, ctypes.c_int,
+                                                                      ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                                      ctypes.c_int, vp, ctypes.c_int, vp, vp]),
     "d3d_rotate_iou_eval": (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp]),
     "d3d_boxes_iou_3d": (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                         ctypes.c_int, ctypes.c_int, vp, vp]),

@@ -123,19 +123,42 @@ __device__ __forceinline__ void roi_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 static constexpr int kRoiWaves = 4;  // waves per RoI (8 measured the same; what helps is waves per SIMD, see kRoiG)
+// One launch serves every pyramid level: a RoI's workgroup picks the map of roi_levels[n] (a launch per level leaves
+// the workgroups of the other levels' RoIs to exit at once -- with two levels each launch fills half the wave slots).
+struct RoiLevel {
+  const HashEntry *tab;   // null: this level is not pooled by the launch
+  const float *feats;
+  const int32_t *extent;  // occupied extent of the grid on the device, or null: H, W, Z below
+  int cap, H, W, Z;
+  float scale;
+};
+static constexpr int kRoiMaxLevels = 4;
+struct RoiLevels {
+  RoiLevel v[kRoiMaxLevels];
+};
 __global__ __launch_bounds__(kRoiWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_roi_sparse(
-    const HashEntry *__restrict__ tab, int cap, const float *__restrict__ feats, int C, int H, int W, int Z,
-    const int32_t *__restrict__ extent, const float *__restrict__ rois, const int32_t *__restrict__ roi_levels,
-    int level, float spatial_scale, int PH, int PW, int PZ, int sampling_ratio, int layout, float *__restrict__ out) {
-  if (extent) {  // crop = occupied extent of the grid, read on the device (no host round trip)
-    H = extent[0];
-    W = extent[1];
-    Z = extent[2];
+    RoiLevels lv, int C, const float *__restrict__ rois, const int32_t *__restrict__ roi_levels,
+    int PH, int PW, int PZ, int sampling_ratio, int layout, float *__restrict__ out) {
+  const int n = blockIdx.x, cc = blockIdx.y;
+  const int l = roi_levels ? __builtin_amdgcn_readfirstlane(roi_levels[n]) : 0;
+  if (l < 0 || l >= kRoiMaxLevels) return;   // -1: a padding row (d3d_roi_prepare_counted)
+  RoiLevel L = lv.v[0];                       // selects, not an indexed copy of the argument block
+  if (l == 1) L = lv.v[1];
+  if (l == 2) L = lv.v[2];
+  if (l == 3) L = lv.v[3];
+  if (!L.tab) return;                         // pooled from another pyramid level (by another launch)
+  const HashEntry *__restrict__ tab = L.tab;
+  const float *__restrict__ feats = L.feats;
+  const int cap = L.cap;
+  const float spatial_scale = L.scale;
+  int H = L.H, W = L.W, Z = L.Z;
+  if (L.extent) {  // crop = occupied extent of the grid, read on the device (no host round trip)
+    H = L.extent[0];
+    W = L.extent[1];
+    Z = L.extent[2];
   }
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   __shared__ int2 list[kRoiWaves][kRoiG][64];  // (row, weight bits) of the taps that exist
-  const int n = blockIdx.x, cc = blockIdx.y;
-  if (roi_levels && roi_levels[n] != level) return;  // pooled from another pyramid level
   const int NB = PH * PW * PZ;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const RoiGeom g = roi_geom(rois + (size_t)n * 8, spatial_scale, PH, PW, PZ, sampling_ratio);
@@ -465,13 +488,9 @@ int d3d_roi_align_rotated_3d_forward(const float *input, int B, int C, int H, in
   return D3D_OK;
 }
 
-int d3d_roi_align_rotated_3d_sparse_forward(d3d_meta *m, const int *size, const float *feats, int C,
-                                            const int *crop, const float *rois, int K,
-                                            float spatial_scale, int ph, int pw, int pz,
-                                            int sampling_ratio, const int *roi_levels, int level, int layout,
-                                            float *out, void *stream) {
-  hipStream_t s = (hipStream_t)stream;
-  D3D_REQUIRE(m && size && C > 0 && K >= 0 && ph > 0 && pw > 0 && pz > 0, "roi_align_sparse: bad arguments");
+// fills lv (one pyramid level of a pooling launch) from the grid of spatial size `size`
+static int roi_level_of(d3d_meta *m, const int *size, const float *feats, const int *crop, float spatial_scale,
+                        hipStream_t s, RoiLevel *lv) {
   std::map<Size3, Grid>::iterator it;
   bool have_grid;
   {
@@ -483,9 +502,6 @@ int d3d_roi_align_rotated_3d_sparse_forward(d3d_meta *m, const int *size, const 
     set_error("roi_align_sparse: no grid of spatial size [%d,%d,%d]", size[0], size[1], size[2]);
     return D3D_ERR_STATE;
   }
-  if (K == 0) return D3D_OK;
-  D3D_REQUIRE(feats && rois && out, "roi_align_sparse: null pointer");
-  D3D_REQUIRE(layout == 0 || layout == 1, "roi_align_sparse: layout must be 0 ([K,C,ph,pw,pz]) or 1 ([K,ph,pw,C,pz])");
   Grid &g = it->second;
   const int32_t *extent = nullptr;
   if (!crop) {  // NULL crop: the grid's own occupied extent, computed once on the device
@@ -493,9 +509,48 @@ int d3d_roi_align_rotated_3d_sparse_forward(d3d_meta *m, const int *size, const 
     if (rc) return rc;
     extent = g.extent;
   }
-  hipLaunchKernelGGL(k_roi_sparse, dim3(K, (C + kRoiCch - 1) / kRoiCch), dim3(kRoiWaves * 64), 0, s, g.tab, g.cap, feats, C,
-                     crop ? crop[0] : 0, crop ? crop[1] : 0, crop ? crop[2] : 0, extent, rois, roi_levels, level,
-                     spatial_scale, ph, pw, pz, sampling_ratio, layout, out);
+  *lv = {g.tab, feats, extent, g.cap, crop ? crop[0] : 0, crop ? crop[1] : 0, crop ? crop[2] : 0, spatial_scale};
+  return D3D_OK;
+}
+
+int d3d_roi_align_rotated_3d_sparse_forward(d3d_meta *m, const int *size, const float *feats, int C,
+                                            const int *crop, const float *rois, int K,
+                                            float spatial_scale, int ph, int pw, int pz,
+                                            int sampling_ratio, const int *roi_levels, int level, int layout,
+                                            float *out, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(m && size && C > 0 && K >= 0 && ph > 0 && pw > 0 && pz > 0, "roi_align_sparse: bad arguments");
+  D3D_REQUIRE(!roi_levels || (level >= 0 && level < kRoiMaxLevels), "roi_align_sparse: level %d (< %d)", level, kRoiMaxLevels);
+  RoiLevels lv = {};
+  if (int rc = roi_level_of(m, size, feats, crop, spatial_scale, s, &lv.v[roi_levels ? level : 0])) return rc;
+  if (K == 0) return D3D_OK;
+  D3D_REQUIRE(feats && rois && out, "roi_align_sparse: null pointer");
+  D3D_REQUIRE(layout == 0 || layout == 1, "roi_align_sparse: layout must be 0 ([K,C,ph,pw,pz]) or 1 ([K,ph,pw,C,pz])");
+  hipLaunchKernelGGL(k_roi_sparse, dim3(K, (C + kRoiCch - 1) / kRoiCch), dim3(kRoiWaves * 64), 0, s, lv, C, rois,
+                     roi_levels, ph, pw, pz, sampling_ratio, layout, out);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+int d3d_roi_align_rotated_3d_sparse_forward_levels(d3d_meta *m, int n_levels, const int *sizes_host,
+                                                   const float *const *feats_host, int C, const float *scales_host,
+                                                   const float *rois, int K, int ph, int pw, int pz, int sampling_ratio,
+                                                   const int *roi_levels, int layout, float *out, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(m && sizes_host && feats_host && scales_host && n_levels >= 1 && n_levels <= kRoiMaxLevels,
+              "roi_align_sparse_levels: 1..%d levels", kRoiMaxLevels);
+  D3D_REQUIRE(C > 0 && K >= 0 && ph > 0 && pw > 0 && pz > 0 && (roi_levels || n_levels == 1),
+              "roi_align_sparse_levels: bad arguments");
+  D3D_REQUIRE(layout == 0 || layout == 1, "roi_align_sparse: layout must be 0 ([K,C,ph,pw,pz]) or 1 ([K,ph,pw,C,pz])");
+  RoiLevels lv = {};
+  for (int l = 0; l < n_levels; l++) {
+    D3D_REQUIRE(feats_host[l], "roi_align_sparse_levels: null feature pointer of level %d", l);
+    if (int rc = roi_level_of(m, sizes_host + 3 * l, feats_host[l], nullptr, scales_host[l], s, &lv.v[l])) return rc;
+  }
+  if (K == 0) return D3D_OK;
+  D3D_REQUIRE(rois && out, "roi_align_sparse_levels: null pointer");
+  hipLaunchKernelGGL(k_roi_sparse, dim3(K, (C + kRoiCch - 1) / kRoiCch), dim3(kRoiWaves * 64), 0, s, lv, C, rois,
+                     roi_levels, ph, pw, pz, sampling_ratio, layout, out);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }

@@ -27,7 +27,8 @@ from . import sparseconvnet as scn
 from . import training as T
 from .config import class_to_label
 from .timeline import mark
-from .roi_align_rotated_3d import roi_align_rotated_3d_sparse, roi_align_rotated_3d_sparse_into, roi_prepare
+from .roi_align_rotated_3d import (roi_align_rotated_3d_sparse, roi_align_rotated_3d_sparse_into,
+                                    roi_align_rotated_3d_sparse_levels_into, roi_prepare)
 from .sparseconvnet import SCN
 
 
@@ -434,6 +435,9 @@ def convert_to_roi_format(boxes_yxzb):
     return rois
 
 
+_ROI_ONE_LAUNCH = os.environ.get("D3D_ROI_LAUNCHES", "one") != "per-level"   # "per-level": one launch per map (A/B)
+
+
 class Pooler(nn.Module):
     """modeling/poolers_3d.py:57-69,73-168 on sparse maps (no dense intermediate)."""
 
@@ -457,6 +461,9 @@ class Pooler(nn.Module):
         K, C = rois.shape[0], x[0].features.shape[1]
         out = torch.empty((K, ph, pw, C, pz) if channels_inner else (K, C, ph, pw, pz), dtype=torch.float32,
                           device=rois.device)
+        if _ROI_ONE_LAUNCH and len(x) <= 4 and all(f.metadata is x[0].metadata for f in x):
+            return roi_align_rotated_3d_sparse_levels_into(out, x, rois, self.scales, self.sampling_ratio, levels,
+                                                           channels_inner=channels_inner)
         for level, (fmap, scale) in enumerate(zip(x, self.scales)):       # crop = occupied extent, found on the device
             roi_align_rotated_3d_sparse_into(out, fmap, rois, scale, self.sampling_ratio, crop=None,
                                              roi_levels=levels, level=level, channels_inner=channels_inner)

@@ -117,6 +117,30 @@ def roi_align_rotated_3d_sparse_into(out, feat_s3d, rois, spatial_scale, samplin
     return out
 
 
+def roi_align_rotated_3d_sparse_levels_into(out, maps, rois, scales, sampling_ratio, roi_levels, channels_inner=True):
+    """All levels of the multi-level pooler in ONE launch (d3d_roi_align_rotated_3d_sparse_forward_levels): RoI i is
+    pooled from maps[roi_levels[i]] into out[i]; rows with another level value (-1: padding) are left untouched."""
+    import ctypes
+    fs = [m.features.contiguous() for m in maps]
+    r = rois.detach().to(torch.float32).contiguous()
+    require_gpu(r, out, *fs)
+    assert out.is_contiguous() and out.dtype == torch.float32 and out.shape[0] == r.shape[0]
+    if channels_inner:
+        _, ph, pw, C, pz = out.shape
+    else:
+        _, C, ph, pw, pz = out.shape
+    assert all(f.shape[1] == C and f.dtype == torch.float32 for f in fs) and 1 <= len(fs) <= 4
+    assert all(m.metadata is maps[0].metadata for m in maps)
+    if roi_levels is not None:
+        assert roi_levels.dtype == torch.int32 and roi_levels.is_contiguous() and roi_levels.shape[0] == r.shape[0]
+    sizes = ints(tuple(int(v) for m in maps for v in m.spatial_size.tolist()))
+    check(lib().d3d_roi_align_rotated_3d_sparse_forward_levels(
+        maps[0].metadata._h, len(fs), sizes, (ctypes.c_void_p * len(fs))(*[f.data_ptr() for f in fs]), C,
+        floats(scales), ptr(r), r.shape[0], ph, pw, pz, int(sampling_ratio), ptr(roi_levels),
+        1 if channels_inner else 0, ptr(out), stream_of()))
+    return out
+
+
 def roi_prepare(boxes_metric, voxel_scale, scales, canonical_size, batch_ids=None, count=None):
     """d3d_roi_prepare: metric yx_zb proposals [K,7] -> (rois [K,8] in pixels, levels int32 [K] or None for a single
     level) in one launch; equals convert_metric_to_pixel + convert_to_roi_format + Pooler.map_levels bit for bit.

@@ -356,6 +356,16 @@ int d3d_roi_align_rotated_3d_sparse_forward(d3d_meta *m, const int *spatial_size
                                             const float *rois, int K, float spatial_scale, int ph,
                                             int pw, int pz, int sampling_ratio, const int *roi_levels,
                                             int level, int layout, float *out, void *stream);
+/* ... all levels of the pooler (poolers_3d.py:150-168) in ONE launch: RoI i is pooled from the map of level
+ * roi_levels[i] (0 <= level < n_levels <= 4; any other value, e.g. the -1 of d3d_roi_prepare_counted, leaves its slot
+ * untouched).  sizes_host [n_levels*3] spatial sizes of the maps, feats_host[l] device pointer of map l's features
+ * [n_active_l, C], scales_host[l] its spatial scale; the occupied extent of every map is found on the device.
+ * roi_levels may be NULL only for n_levels == 1.                                                                      */
+int d3d_roi_align_rotated_3d_sparse_forward_levels(d3d_meta *m, int n_levels, const int *sizes_host,
+                                                   const float *const *feats_host, int C, const float *scales_host,
+                                                   const float *rois, int K, int ph, int pw, int pz,
+                                                   int sampling_ratio, const int *roi_levels, int layout, float *out,
+                                                   void *stream);
 
 /* a17. rotate_iou_gpu_eval (second/core/non_max_suppression/nms_gpu.py:614-664) incl.
  * check_same_boxes: boxes [N,5], query [K,5] -> out [N,K].                                   */
