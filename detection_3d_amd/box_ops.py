@@ -174,6 +174,37 @@ def nms_3d_clamped(bbox3d, scores, nms_thresh, nms_aug_thickness=None, max_propo
                          iou_threshold=nms_thresh, flag=flag)
 
 
+_UNIT_WEIGHTS = None
+
+
+def box_decode_rows(box_encodings, anchors, rows, bbox_xform_clip=10000.0):
+    """box_decode(box_encodings[rows], anchors[rows]) (unit weights, one class) without the two gathers:
+    d3d_box_decode_rows.  rows int64 [n] on the device."""
+    global _UNIT_WEIGHTS
+    enc, anc = _f32c(box_encodings), _f32c(anchors)
+    require_gpu(enc, anc, rows)
+    assert enc.shape[1] == 7 and anc.shape[1] == 7 and enc.shape[0] == anc.shape[0] and rows.dtype == torch.int64
+    if _UNIT_WEIGHTS is None:
+        _UNIT_WEIGHTS = floats((1.0,) * 7)
+    out = torch.empty((rows.shape[0], 7), dtype=torch.float32, device=enc.device)
+    check(lib().d3d_box_decode_rows(ptr(enc), ptr(anc), ptr(rows), rows.shape[0], _UNIT_WEIGHTS, float(bbox_xform_clip),
+                                    ptr(out), stream_of()))
+    return out
+
+
+def gather_kept(boxes, scores, keep, n_keep, rows_out, min_size):
+    """d3d_gather_kept: -> (boxes [rows_out, 7] with clamped sizes, scores [rows_out]) of the NMS survivors keep[:n_keep]
+    (n_keep int32 [1] still on the device), padded with candidate 0."""
+    require_gpu(boxes, scores, keep, n_keep)
+    assert boxes.dtype == torch.float32 and scores.dtype == torch.float32 and keep.dtype == torch.int32
+    assert n_keep.dtype == torch.int32 and boxes.shape[0] > 0 and keep.numel() >= rows_out
+    ob = torch.empty((rows_out, 7), dtype=torch.float32, device=boxes.device)
+    os_ = torch.empty((rows_out,), dtype=torch.float32, device=boxes.device)
+    check(lib().d3d_gather_kept(ptr(boxes), ptr(scores), ptr(keep), ptr(n_keep), rows_out, float(min_size), ptr(ob),
+                                ptr(os_), stream_of()))
+    return ob, os_
+
+
 def box_decode(box_encodings, anchors, weights=(1.0,) * 7, bbox_xform_clip=10000.0):
     """BoxCoder3D.decode with smooth_dim=True; box_encodings [n, 7*nc], anchors [n, 7]."""
     enc, anc = _f32c(box_encodings), _f32c(anchors)

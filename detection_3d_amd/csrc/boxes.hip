@@ -563,10 +563,11 @@ __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long *__re
 // a14. BoxCoder3D.decode
 __global__ void k_box_decode(const float *__restrict__ enc, const float *__restrict__ anchors, int n,
                              float w0, float w1, float w2, float w3, float w4, float w5, float w6,
-                             float clip, float *__restrict__ out) {
+                             float clip, float *__restrict__ out, const int64_t *__restrict__ rows) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float *e = enc + (size_t)i * 7, *a = anchors + (size_t)i * 7;
+  const size_t src = rows ? (size_t)rows[i] : (size_t)i;   // rows: the top-k selection, gathered here
+  const float *e = enc + src * 7, *a = anchors + src * 7;
   const float w[7] = {w0, w1, w2, w3, w4, w5, w6};
   float t[7];
 #pragma unroll
@@ -585,6 +586,25 @@ __global__ void k_box_decode(const float *__restrict__ enc, const float *__restr
   const float pi = 3.14159265358979323846f;
   const float rg = t[6] + ra;
   o[6] = rg - floorf(rg / pi + 0.5f) * pi;
+}
+
+// survivors of the RPN's NMS into a list padded to P rows: out row i < *n_keep is box / score keep[i] with its sizes
+// clamped from below (BoxList3D.clamp_size), the other rows repeat row 0 of the candidates (never pooled)
+__global__ void k_gather_kept(const float *__restrict__ boxes, const float *__restrict__ scores,
+                              const int32_t *__restrict__ keep, const int32_t *__restrict__ n_keep, int P,
+                              float min_size, float *__restrict__ out_boxes, float *__restrict__ out_scores) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const int j = i < *n_keep ? keep[i] : 0;
+  const float *b = boxes + (size_t)j * 7;
+  float *o = out_boxes + (size_t)i * 7;
+#pragma unroll
+  for (int k = 0; k < 7; k++) {
+    float v = b[k];
+    if (k >= 3 && k < 6) v = v < min_size ? min_size : v;   // torch.clamp(min=): a NaN stays
+    o[k] = v;
+  }
+  out_scores[i] = scores[j];
 }
 
 }  // namespace d3d
@@ -847,7 +867,31 @@ int d3d_box_decode(const float *enc, const float *anchors, int n, const float *w
   if (n == 0) return D3D_OK;
   D3D_REQUIRE(enc && anchors && out && weights_host && n > 0, "box_decode: bad arguments");
   const float *w = weights_host;
-  hipLaunchKernelGGL(k_box_decode, dim3((n + 255) / 256), dim3(256), 0, s, enc, anchors, n, w[0], w[1], w[2], w[3], w[4], w[5], w[6], clip, out);
+  hipLaunchKernelGGL(k_box_decode, dim3((n + 255) / 256), dim3(256), 0, s, enc, anchors, n, w[0], w[1], w[2], w[3], w[4], w[5], w[6], clip, out,
+                     (const int64_t *)nullptr);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+int d3d_box_decode_rows(const float *enc, const float *anchors, const int64_t *rows, int n, const float *weights_host,
+                        float clip, float *out, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) return D3D_OK;
+  D3D_REQUIRE(enc && anchors && rows && out && weights_host && n > 0, "box_decode_rows: bad arguments");
+  const float *w = weights_host;
+  hipLaunchKernelGGL(k_box_decode, dim3((n + 255) / 256), dim3(256), 0, s, enc, anchors, n, w[0], w[1], w[2], w[3], w[4], w[5], w[6], clip, out,
+                     rows);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+int d3d_gather_kept(const float *boxes, const float *scores, const int32_t *keep, const int32_t *n_keep_dev, int P,
+                    float min_size, float *out_boxes, float *out_scores, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (P == 0) return D3D_OK;
+  D3D_REQUIRE(boxes && scores && keep && n_keep_dev && out_boxes && out_scores && P > 0, "gather_kept: bad arguments");
+  hipLaunchKernelGGL(k_gather_kept, dim3((P + 255) / 256), dim3(256), 0, s, boxes, scores, keep, n_keep_dev, P, min_size,
+                     out_boxes, out_scores);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }

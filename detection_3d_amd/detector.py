@@ -311,12 +311,14 @@ class RPNModule(nn.Module):
         scores = objectness.reshape(-1).sigmoid()
         k = min(pre, scores.shape[0])
         scores_k, idx = scores.topk(k, dim=0, sorted=True)                      # inference_3d.py:109
-        proposals = box_ops.box_decode(box_regression[idx], anchors[idx])       # :123
-        if defer and 0 < k <= 2000 and post > 100:
+        if defer and 0 < k <= 2000 and post > 100 and box_regression.shape[1] == 7:
+            proposals = box_ops.box_decode_rows(box_regression, anchors, idx)   # :123, the two gathers inside
             keep, nk = box_ops.nms_3d_batched(proposals, None, None, k, self.nms_thresh, self.nms_aug_thickness, post)
             readback = PaddedProposals.start_readback(nk)
-            rows = keep[0, :min(post, k)].long().clamp_(0, k - 1)               # past the count: any valid row
-            return PaddedProposals(proposals[rows], scores_k[rows], nk, readback)
+            # the survivors, padded to `post` rows, sizes clamped (BoxList3D.clamp_size): one launch
+            boxes, scores_p = box_ops.gather_kept(proposals, scores_k, keep, nk, min(post, k), 0.001)
+            return PaddedProposals(boxes, scores_p, nk, readback)
+        proposals = box_ops.box_decode(box_regression[idx], anchors[idx])       # :123
         keep = box_ops.nms_3d_presorted(proposals, self.nms_thresh, self.nms_aug_thickness, max_proposals=post,
                                         flag='rpn_post')                        # scores_k is sorted: no re-sort
         return proposals[keep], scores_k[keep]
@@ -549,7 +551,7 @@ class FPN2MLPFeatureExtractor(nn.Module):
                 and (not padded or len(self.pooler.scales) > 1))
 
     def forward_padded(self, x0, padded):
-        """PaddedProposals (sizes already clamped) -> (box features [n, rep], proposals [n, 7], scores [n]): the pooler is
+        """PaddedProposals (sizes clamped by d3d_gather_kept) -> (box features [n, rep], proposals [n, 7], scores [n]): the pooler is
         enqueued over all padded rows, then the count is read back and the head runs over the real ones."""
         pooled = self.pooler.pool_metric(x0, padded.boxes, self.voxel_scale, channels_inner=True, count=padded.count)
         proposals, scores = padded.resolve()
@@ -920,7 +922,6 @@ class SparseRCNN(nn.Module):
         mark("proposals")
         if isinstance(out, PaddedProposals):
             # the pooler goes out behind the NMS; the survivor count is read back while it runs
-            out.boxes[:, 3:6] = torch.clamp(out.boxes[:, 3:6], min=0.001)       # BoxList3D.clamp_size
             result, proposals, objectness = self.roi_heads.box.forward_padded(roi_features, out)
             mark("detections")
             if return_intermediates:

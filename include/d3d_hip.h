@@ -418,6 +418,16 @@ int d3d_post_select(const int32_t *keep, const int32_t *n_keep, int segments, in
 /* a14. BoxCoder3D.decode (maskrcnn_benchmark/modeling/box_coder_3d.py:38-65). */
 int d3d_box_decode(const float *enc, const float *anchors, int n, const float *weights_host,
                    float clip, float *out, void *stream);
+/* ... of the rows the RPN's top-k selected (rpn/inference_3d.py:109-123: `box_regression[topk_idx]`,
+ * `concat_anchors[topk_idx]`, then decode): out[i] = decode(enc[rows[i]], anchors[rows[i]]), rows int64 [n] on the device. */
+int d3d_box_decode_rows(const float *enc, const float *anchors, const int64_t *rows, int n,
+                        const float *weights_host, float clip, float *out, void *stream);
+/* The survivors of the RPN's NMS (rpn/inference_3d.py:127-131 `boxlist = boxlist[keep]`) as a list padded to P rows
+ * while their count is still on the device: for i < *n_keep_dev, out_boxes[i] = boxes[keep[i]] with the three sizes
+ * clamped to >= min_size (BoxList3D.clamp_size, structures/bounding_box_3d.py) and out_scores[i] = scores[keep[i]];
+ * rows >= *n_keep_dev repeat candidate 0 (d3d_roi_prepare_counted switches them off).  keep int32 (device).        */
+int d3d_gather_kept(const float *boxes, const float *scores, const int32_t *keep, const int32_t *n_keep_dev, int P,
+                    float min_size, float *out_boxes, float *out_scores, void *stream);
 
 #ifdef __cplusplus
 }
