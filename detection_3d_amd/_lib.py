@@ -136,7 +136,7 @@ _SIGS = {
                                       vp, vp]),
     "d3d_box_decode_rows": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.c_float,
                                            vp, vp]),
-    "d3d_gather_kept": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_float, vp, vp, vp]),
+    "d3d_gather_kept": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_float, vp, vp, vp, vp]),
     "d3d_plan_stats": (ctypes.c_int, [vp, ctypes.c_int, c_int_p, c_int_p, c_int_p, ctypes.POINTER(ctypes.c_long),
                                       ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long), vp]),
     # storage-type aware forms (d3d_dtype: 0 fp32, 1 bf16)

@@ -192,16 +192,19 @@ def box_decode_rows(box_encodings, anchors, rows, bbox_xform_clip=10000.0):
     return out
 
 
-def gather_kept(boxes, scores, keep, n_keep, rows_out, min_size):
+def gather_kept(boxes, scores, keep, n_keep, rows_out, min_size, count_host=None):
     """d3d_gather_kept: -> (boxes [rows_out, 7] with clamped sizes, scores [rows_out]) of the NMS survivors keep[:n_keep]
-    (n_keep int32 [1] still on the device), padded with candidate 0."""
+    (n_keep int32 [1] still on the device), padded with candidate 0.  count_host: pinned int32 [1] host tensor that
+    receives n_keep by a store of the kernel (read it after an event recorded behind this call)."""
+    if count_host is not None:
+        assert count_host.dtype == torch.int32 and count_host.is_pinned()
     require_gpu(boxes, scores, keep, n_keep)
     assert boxes.dtype == torch.float32 and scores.dtype == torch.float32 and keep.dtype == torch.int32
     assert n_keep.dtype == torch.int32 and boxes.shape[0] > 0 and keep.numel() >= rows_out
     ob = torch.empty((rows_out, 7), dtype=torch.float32, device=boxes.device)
     os_ = torch.empty((rows_out,), dtype=torch.float32, device=boxes.device)
     check(lib().d3d_gather_kept(ptr(boxes), ptr(scores), ptr(keep), ptr(n_keep), rows_out, float(min_size), ptr(ob),
-                                ptr(os_), stream_of()))
+                                ptr(os_), ptr(count_host), stream_of()))
     return ob, os_
 
 

@@ -592,8 +592,12 @@ __global__ void k_box_decode(const float *__restrict__ enc, const float *__restr
 // clamped from below (BoxList3D.clamp_size), the other rows repeat row 0 of the candidates (never pooled)
 __global__ void k_gather_kept(const float *__restrict__ boxes, const float *__restrict__ scores,
                               const int32_t *__restrict__ keep, const int32_t *__restrict__ n_keep, int P,
-                              float min_size, float *__restrict__ out_boxes, float *__restrict__ out_scores) {
+                              float min_size, float *__restrict__ out_boxes, float *__restrict__ out_scores,
+                              int32_t *__restrict__ count_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // the count, for the host: a store to pinned host memory that an event recorded behind this launch makes visible --
+  // no copy engine and no second stream between the NMS and the host
+  if (i == 0 && count_out) __hip_atomic_store(count_out, *n_keep, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   if (i >= P) return;
   const int j = i < *n_keep ? keep[i] : 0;
   const float *b = boxes + (size_t)j * 7;
@@ -886,12 +890,12 @@ int d3d_box_decode_rows(const float *enc, const float *anchors, const int64_t *r
 }
 
 int d3d_gather_kept(const float *boxes, const float *scores, const int32_t *keep, const int32_t *n_keep_dev, int P,
-                    float min_size, float *out_boxes, float *out_scores, void *stream) {
+                    float min_size, float *out_boxes, float *out_scores, int32_t *count_out, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   if (P == 0) return D3D_OK;
   D3D_REQUIRE(boxes && scores && keep && n_keep_dev && out_boxes && out_scores && P > 0, "gather_kept: bad arguments");
   hipLaunchKernelGGL(k_gather_kept, dim3((P + 255) / 256), dim3(256), 0, s, boxes, scores, keep, n_keep_dev, P, min_size,
-                     out_boxes, out_scores);
+                     out_boxes, out_scores, count_out);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }

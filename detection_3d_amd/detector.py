@@ -248,30 +248,23 @@ class PaddedProposals(object):
     """The RPN's proposals of one example before the survivor count of its NMS is read back: `boxes` [P, 7] and `scores`
     [P] padded to P = FPN_POST_NMS_TOP_N rows, `count` int32 [1] on the device = the real rows (the first ones)."""
 
-    _lanes = {}     # (device, caller's stream) -> (copy stream, pinned word, event "count written", event "count copied")
+    _lanes = {}     # (device, caller's stream) -> (pinned word the gather kernel stores the count to, event behind it)
 
     def __init__(self, boxes, scores, count, readback=None):
         self.boxes, self.scores, self.count, self._readback = boxes, scores, count, readback
 
     @classmethod
-    def start_readback(cls, count):
-        """Copies `count` (just enqueued on the caller's stream) to a pinned word on a side stream, so that the host
-        can wait for it alone -- not for the pooler launches that follow it on the caller's stream."""
+    def count_lane(cls, dev):
+        """-> (pinned int32 word, event) of the caller's stream: d3d_gather_kept stores the survivor count to the word,
+        the event is recorded behind that launch -- the host waits for it alone, not for the pooler launches that
+        follow on the stream (and no copy engine or second stream sits between the NMS and the host)."""
         from ._lib import raw_stream
-        dev = count.device
         key = (dev.index, raw_stream(dev))
         lane = cls._lanes.get(key)
         if lane is None:
-            lane = cls._lanes[key] = (torch.cuda.Stream(device=dev, priority=-1),
-                                      torch.empty(1, dtype=torch.int32).pin_memory(),
-                                      torch.cuda.Event(), torch.cuda.Event())
-        side, word, written, copied = lane
-        written.record()
-        side.wait_event(written)
-        with torch.cuda.stream(side):
-            word.copy_(count, non_blocking=True)
-            copied.record()
-        return word, copied
+            lane = cls._lanes[key] = (torch.zeros(1, dtype=torch.int32).pin_memory(),
+                                      torch.cuda.Event(blocking=_COUNT_EVENT_BLOCKING))
+        return lane
 
     def resolve(self):
         """the one host synchronisation -> (boxes [n, 7], scores [n])"""
@@ -285,6 +278,7 @@ class PaddedProposals(object):
 
 
 _DEFER_PROPOSALS = os.environ.get("D3D_DEFER_PROPOSALS", "1") != "0"
+_COUNT_EVENT_BLOCKING = os.environ.get("D3D_COUNT_EVENT_BLOCKING", "1") != "0"
 
 
 class RPNModule(nn.Module):
@@ -314,10 +308,12 @@ class RPNModule(nn.Module):
         if defer and 0 < k <= 2000 and post > 100 and box_regression.shape[1] == 7:
             proposals = box_ops.box_decode_rows(box_regression, anchors, idx)   # :123, the two gathers inside
             keep, nk = box_ops.nms_3d_batched(proposals, None, None, k, self.nms_thresh, self.nms_aug_thickness, post)
-            readback = PaddedProposals.start_readback(nk)
-            # the survivors, padded to `post` rows, sizes clamped (BoxList3D.clamp_size): one launch
-            boxes, scores_p = box_ops.gather_kept(proposals, scores_k, keep, nk, min(post, k), 0.001)
-            return PaddedProposals(boxes, scores_p, nk, readback)
+            # the survivors, padded to `post` rows, sizes clamped (BoxList3D.clamp_size): one launch, which also
+            # stores the count to a pinned word for the host
+            word, stored = PaddedProposals.count_lane(proposals.device)
+            boxes, scores_p = box_ops.gather_kept(proposals, scores_k, keep, nk, min(post, k), 0.001, count_host=word)
+            stored.record()
+            return PaddedProposals(boxes, scores_p, nk, (word, stored))
         proposals = box_ops.box_decode(box_regression[idx], anchors[idx])       # :123
         keep = box_ops.nms_3d_presorted(proposals, self.nms_thresh, self.nms_aug_thickness, max_proposals=post,
                                         flag='rpn_post')                        # scores_k is sorted: no re-sort

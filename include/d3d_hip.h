@@ -425,9 +425,11 @@ int d3d_box_decode_rows(const float *enc, const float *anchors, const int64_t *r
 /* The survivors of the RPN's NMS (rpn/inference_3d.py:127-131 `boxlist = boxlist[keep]`) as a list padded to P rows
  * while their count is still on the device: for i < *n_keep_dev, out_boxes[i] = boxes[keep[i]] with the three sizes
  * clamped to >= min_size (BoxList3D.clamp_size, structures/bounding_box_3d.py) and out_scores[i] = scores[keep[i]];
- * rows >= *n_keep_dev repeat candidate 0 (d3d_roi_prepare_counted switches them off).  keep int32 (device).        */
+ * rows >= *n_keep_dev repeat candidate 0 (d3d_roi_prepare_counted switches them off).  keep int32 (device).
+ * count_out (nullable): receives *n_keep_dev by a system-scope store -- pinned host memory: the host reads it after
+ * an event recorded behind this launch, while later launches of the stream (the pooler) are already running.       */
 int d3d_gather_kept(const float *boxes, const float *scores, const int32_t *keep, const int32_t *n_keep_dev, int P,
-                    float min_size, float *out_boxes, float *out_scores, void *stream);
+                    float min_size, float *out_boxes, float *out_scores, int32_t *count_out, void *stream);
 
 #ifdef __cplusplus
 }
