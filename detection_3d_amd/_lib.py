@@ -237,3 +237,20 @@ def require_gpu(*tensors):
             raise D3DError("this op runs on the MI355X only: tensor is on %s (no CPU fallback)" % t.device)
         if t is not None and not t.is_contiguous():
             raise D3DError("tensor must be contiguous")
+
+
+_HOST_WORDS = {}
+_HOST_WORD_BLOCKING = os.environ.get("D3D_COUNT_EVENT_BLOCKING", "1") != "0"
+
+
+def host_word(device, tag):
+    """-> (pinned int32 [1] host tensor, event) of (device, current stream, tag), made once.  A kernel stores a count to
+    the word (pinned host memory is device-visible at the same address), the caller records the event behind that
+    launch and the host waits for the event alone: no copy engine between the kernel and the host, and launches
+    enqueued behind the event do not hold the host up."""
+    key = (device.index, raw_stream(device), tag)
+    w = _HOST_WORDS.get(key)
+    if w is None:
+        w = _HOST_WORDS[key] = (torch.zeros(1, dtype=torch.int32).pin_memory(),
+                                torch.cuda.Event(blocking=_HOST_WORD_BLOCKING))
+    return w

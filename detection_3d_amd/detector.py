@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import box_ops
-from ._lib import check, lib, ptr, stream_of
+from ._lib import check, host_word, lib, ptr, stream_of
 from ._lib import ints as _ints
 from . import sparseconvnet as scn
 from . import training as T
@@ -248,23 +248,10 @@ class PaddedProposals(object):
     """The RPN's proposals of one example before the survivor count of its NMS is read back: `boxes` [P, 7] and `scores`
     [P] padded to P = FPN_POST_NMS_TOP_N rows, `count` int32 [1] on the device = the real rows (the first ones)."""
 
-    _lanes = {}     # (device, caller's stream) -> (pinned word the gather kernel stores the count to, event behind it)
-
     def __init__(self, boxes, scores, count, readback=None):
+        # readback = (pinned word d3d_gather_kept stored the count to, event recorded behind that launch): the host waits
+        # for the event alone, not for the pooler launches that follow it on the stream
         self.boxes, self.scores, self.count, self._readback = boxes, scores, count, readback
-
-    @classmethod
-    def count_lane(cls, dev):
-        """-> (pinned int32 word, event) of the caller's stream: d3d_gather_kept stores the survivor count to the word,
-        the event is recorded behind that launch -- the host waits for it alone, not for the pooler launches that
-        follow on the stream (and no copy engine or second stream sits between the NMS and the host)."""
-        from ._lib import raw_stream
-        key = (dev.index, raw_stream(dev))
-        lane = cls._lanes.get(key)
-        if lane is None:
-            lane = cls._lanes[key] = (torch.zeros(1, dtype=torch.int32).pin_memory(),
-                                      torch.cuda.Event(blocking=_COUNT_EVENT_BLOCKING))
-        return lane
 
     def resolve(self):
         """the one host synchronisation -> (boxes [n, 7], scores [n])"""
@@ -278,7 +265,6 @@ class PaddedProposals(object):
 
 
 _DEFER_PROPOSALS = os.environ.get("D3D_DEFER_PROPOSALS", "1") != "0"
-_COUNT_EVENT_BLOCKING = os.environ.get("D3D_COUNT_EVENT_BLOCKING", "1") != "0"
 
 
 class RPNModule(nn.Module):
@@ -310,7 +296,7 @@ class RPNModule(nn.Module):
             keep, nk = box_ops.nms_3d_batched(proposals, None, None, k, self.nms_thresh, self.nms_aug_thickness, post)
             # the survivors, padded to `post` rows, sizes clamped (BoxList3D.clamp_size): one launch, which also
             # stores the count to a pinned word for the host
-            word, stored = PaddedProposals.count_lane(proposals.device)
+            word, stored = host_word(proposals.device, "rpn")
             boxes, scores_p = box_ops.gather_kept(proposals, scores_k, keep, nk, min(post, k), 0.001, count_host=word)
             stored.record()
             return PaddedProposals(boxes, scores_p, nk, (word, stored))
@@ -655,12 +641,14 @@ class PostProcessor(nn.Module):
             out_b = torch.empty((N, 7), dtype=torch.float32, device=dev)
             out_s = torch.empty((N,), dtype=torch.float32, device=dev)
             out_l = torch.empty((N,), dtype=torch.int64, device=dev)
-            out_n = torch.empty((1,), dtype=torch.int32, device=dev)
+            out_n, stored = host_word(dev, "detections")     # pinned: the kernel's store is the read-back
             boxes = boxes.contiguous()
             check(lib().d3d_post_select(ptr(keep), ptr(nk), nc - 1, n_max, ptr(prob), ptr(boxes), nc,
                                         int(self.detections_per_img), ptr(out_b), ptr(out_s), ptr(out_l), ptr(out_n),
                                         stream_of()))
-            n = int(out_n.item())                                                # the one host synchronisation
+            stored.record()
+            stored.synchronize()                                                 # the one host synchronisation
+            n = int(out_n[0])
             return {"bbox3d": out_b[:n], "scores": out_s[:n], "labels": out_l[:n]}
         s_all = torch.empty((N,), dtype=torch.float32, device=dev)
         flat_all = torch.empty((N,), dtype=torch.int64, device=dev)

@@ -410,7 +410,9 @@ int d3d_post_gather(const int32_t *keep, const int32_t *n_keep, int segments, in
  * the detections-th largest s when 0 < detections < segments * n_max, clamped to >= 0, else 0; every t with
  * s[t] >= thresh is kept IN t ORDER (ties at the threshold all stay, like `cls_scores >= image_thresh`, :146) and
  * out_boxes [n,7] = boxes[keep[t]], out_scores [n] = s[t], out_labels int64 [n] = keep[t] % nc, *out_n (device) = n.
- * Output capacity: segments * n_max rows.  segments * n_max <= d3d_post_select_max().                                */
+ * Output capacity: segments * n_max rows.  segments * n_max <= d3d_post_select_max().                                
+ * out_n (and any other count this header returns through a device pointer) may be pinned host memory: the kernel's
+ * store is then the read-back, visible to the host behind an event recorded after the launch.                          */
 int d3d_post_select_max(void);
 int d3d_post_select(const int32_t *keep, const int32_t *n_keep, int segments, int n_max, const float *prob_flat,
                     const float *boxes, int nc, int detections, float *out_boxes, float *out_scores, int64_t *out_labels,
