@@ -127,6 +127,8 @@ _SIGS = {
     "d3d_nms_batched_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "d3d_anchors": (ctypes.c_int, [vp, c_int_p, ctypes.POINTER(ctypes.c_float), ctypes.c_int,
                                    ctypes.POINTER(ctypes.c_float), ctypes.c_float, vp, vp]),
+    "d3d_anchors_maps": (ctypes.c_int, [vp, ctypes.c_int, c_int_p, ctypes.POINTER(ctypes.c_float), ctypes.c_int,
+                                        ctypes.POINTER(ctypes.c_float), ctypes.c_float, vp, vp]),
     "d3d_rpn_head": (ctypes.c_int, [ctypes.POINTER(vp), c_int_p, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp,
                                     ctypes.c_int, vp, vp, vp]),
     "d3d_rotate_nms_3d_sorted": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, vp, vp, vp,
@@ -134,6 +136,8 @@ _SIGS = {
     "d3d_nms_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "d3d_box_decode": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.c_float,
                                       vp, vp]),
+    "d3d_box_decode_classes": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
+                                              ctypes.c_float, vp, vp]),
     "d3d_box_decode_rows": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.c_float,
                                            vp, vp]),
     "d3d_gather_kept": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_float, vp, vp, vp, vp]),

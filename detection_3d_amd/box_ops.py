@@ -109,7 +109,7 @@ def nms_3d_batched(boxes, order, counts, n_max, iou_threshold, aug_thickness=(0.
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
         _NMS_SCRATCH[_nms_key(dev)] = buf
     keep = torch.empty((B, max(n_max, 1)), dtype=torch.int32, device=dev)
-    nk = torch.zeros(B, dtype=torch.int32, device=dev)
+    nk = torch.empty(B, dtype=torch.int32, device=dev)      # every segment's count is written (zeros for n_max == 0)
     check(lib().d3d_rotate_nms_3d_batched(ptr(boxes), ptr(order), stride, ptr(counts), B, n_max, float(iou_threshold),
                                           float(aug_thickness[0]), float(aug_thickness[1]), int(max_keep or 0),
                                           ptr(keep), ptr(nk), ptr(buf), buf.numel(), stream_of()))
@@ -214,14 +214,11 @@ def box_decode(box_encodings, anchors, weights=(1.0,) * 7, bbox_xform_clip=10000
     require_gpu(enc, anc)
     assert enc.shape[0] == anc.shape[0] and anc.shape[1] == 7
     nc = enc.shape[1] // 7
-    if nc != 1:
-        n = enc.shape[0]
-        enc = enc.view(-1, 7)
-        anc = anc.view(n, 1, 7).repeat(1, nc, 1).view(-1, 7).contiguous()
     out = torch.empty_like(enc)
-    if enc.shape[0]:
+    if enc.shape[0] and nc != 1:        # every class of a row against the row's anchor, no repeated anchor tensor
+        check(lib().d3d_box_decode_classes(ptr(enc), ptr(anc), enc.shape[0], nc, floats(weights), float(bbox_xform_clip),
+                                           ptr(out), stream_of()))
+    elif enc.shape[0]:
         check(lib().d3d_box_decode(ptr(enc), ptr(anc), enc.shape[0], floats(weights), float(bbox_xform_clip),
                                    ptr(out), stream_of()))
-    if nc != 1:
-        out = out.view(-1, nc * 7)
     return out

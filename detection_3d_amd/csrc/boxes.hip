@@ -563,11 +563,12 @@ __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long *__re
 // a14. BoxCoder3D.decode
 __global__ void k_box_decode(const float *__restrict__ enc, const float *__restrict__ anchors, int n,
                              float w0, float w1, float w2, float w3, float w4, float w5, float w6,
-                             float clip, float *__restrict__ out, const int64_t *__restrict__ rows) {
+                             float clip, float *__restrict__ out, const int64_t *__restrict__ rows, int nc) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const size_t src = rows ? (size_t)rows[i] : (size_t)i;   // rows: the top-k selection, gathered here
-  const float *e = enc + src * 7, *a = anchors + src * 7;
+  // nc > 1: enc holds nc class-wise encodings per anchor row (box_coder_3d.py decode of [n, 7 nc])
+  const float *e = enc + src * 7, *a = anchors + (src / (size_t)nc) * 7;
   const float w[7] = {w0, w1, w2, w3, w4, w5, w6};
   float t[7];
 #pragma unroll
@@ -872,7 +873,7 @@ int d3d_box_decode(const float *enc, const float *anchors, int n, const float *w
   D3D_REQUIRE(enc && anchors && out && weights_host && n > 0, "box_decode: bad arguments");
   const float *w = weights_host;
   hipLaunchKernelGGL(k_box_decode, dim3((n + 255) / 256), dim3(256), 0, s, enc, anchors, n, w[0], w[1], w[2], w[3], w[4], w[5], w[6], clip, out,
-                     (const int64_t *)nullptr);
+                     (const int64_t *)nullptr, 1);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }
@@ -884,7 +885,21 @@ int d3d_box_decode_rows(const float *enc, const float *anchors, const int64_t *r
   D3D_REQUIRE(enc && anchors && rows && out && weights_host && n > 0, "box_decode_rows: bad arguments");
   const float *w = weights_host;
   hipLaunchKernelGGL(k_box_decode, dim3((n + 255) / 256), dim3(256), 0, s, enc, anchors, n, w[0], w[1], w[2], w[3], w[4], w[5], w[6], clip, out,
-                     rows);
+                     rows, 1);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+int d3d_box_decode_classes(const float *enc, const float *anchors, int n, int nc, const float *weights_host, float clip,
+                           float *out, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) return D3D_OK;
+  D3D_REQUIRE(enc && anchors && out && weights_host && n > 0 && nc >= 1, "box_decode_classes: bad arguments");
+  const float *w = weights_host;
+  const long total = (long)n * nc;
+  D3D_REQUIRE(total < (1L << 31), "box_decode_classes: %ld boxes", total);
+  hipLaunchKernelGGL(k_box_decode, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, enc, anchors, (int)total, w[0], w[1], w[2], w[3],
+                     w[4], w[5], w[6], clip, out, (const int64_t *)nullptr, nc);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }

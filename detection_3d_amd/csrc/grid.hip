@@ -1000,6 +1000,33 @@ __global__ void k_anchors(const int32_t *__restrict__ loc, int n, int A, AnchorB
   o[5] = 0.f + b[5];
   o[6] = 0.f + b[6];
 }
+// ... for up to kAnchorMaps maps in one launch: map m's sites are rows start[m] .. start[m+1]-1 of the row space
+static constexpr int kAnchorMaps = 6, kAnchorA = 4;
+struct AnchorMaps {
+  const int32_t *loc[kAnchorMaps];
+  int start[kAnchorMaps + 1];
+  float stride[kAnchorMaps][3];
+  float base[kAnchorMaps][kAnchorA * 7];
+  int n_maps;
+};
+__global__ void k_anchors_maps(AnchorMaps am, int A, float vs, float *__restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= am.start[am.n_maps] * A) return;
+  const int row = t / A, a = t - row * A;
+  int m = 0;
+  while (m + 1 < am.n_maps && row >= am.start[m + 1]) m++;
+  const int32_t *p = am.loc[m] + (size_t)(row - am.start[m]) * 4;
+  const float *b = am.base[m] + a * 7;
+  float *o = out + (size_t)t * 7;
+  // the same operations, in the same order, as k_anchors
+  o[0] = (float)p[0] / vs * am.stride[m][0] + b[0];
+  o[1] = (float)p[1] / vs * am.stride[m][1] + b[1];
+  o[2] = (float)p[2] / vs * am.stride[m][2] + b[2];
+  o[3] = 0.f + b[3];
+  o[4] = 0.f + b[4];
+  o[5] = 0.f + b[5];
+  o[6] = 0.f + b[6];
+}
 __global__ void k_sparse_to_dense(const float *__restrict__ in, int planes,
                                   const int32_t *__restrict__ loc, int n, int sx, int sy, int sz,
                                   float *__restrict__ out) {
@@ -1551,6 +1578,36 @@ int d3d_anchors(d3d_meta *m, const int *size, const float *base_host, int A, con
   for (int i = 0; i < A * 7; i++) base.v[i] = base_host[i];
   hipLaunchKernelGGL(k_anchors, grid1d((long)g->n * A), dim3(256), 0, s, g->loc, g->n, A, base, voxel_scale,
                      stride_host[0], stride_host[1], stride_host[2], out);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+int d3d_anchors_maps(d3d_meta *m, int n_maps, const int *sizes_host, const float *bases_host, int A,
+                     const float *strides_host, float voxel_scale, float *out, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(m && sizes_host && bases_host && strides_host && n_maps >= 1 && n_maps <= kAnchorMaps && A >= 1 &&
+                  A <= kAnchorA && voxel_scale > 0,
+              "anchors_maps: 1..%d maps, 1..%d anchors per site", kAnchorMaps, kAnchorA);
+  AnchorMaps am = {};
+  long n = 0;
+  for (int i = 0; i < n_maps; i++) {
+    Grid *g = find_grid(m, sizes_host + 3 * i);
+    if (!g) {
+      set_error("anchors: no grid of spatial size [%d,%d,%d]", sizes_host[3 * i], sizes_host[3 * i + 1], sizes_host[3 * i + 2]);
+      return D3D_ERR_STATE;
+    }
+    am.loc[i] = g->loc;
+    am.start[i] = (int)n;
+    n += g->n;
+    for (int d = 0; d < 3; d++) am.stride[i][d] = strides_host[3 * i + d];
+    for (int j = 0; j < A * 7; j++) am.base[i][j] = bases_host[(size_t)i * A * 7 + j];
+  }
+  D3D_REQUIRE(n * A * 7 < (1L << 31), "anchors_maps: %ld sites", n);
+  for (int i = n_maps; i <= kAnchorMaps; i++) am.start[i] = (int)n;
+  am.n_maps = n_maps;
+  if (n == 0) return D3D_OK;
+  D3D_REQUIRE(out, "null output");
+  hipLaunchKernelGGL(k_anchors_maps, grid1d(n * A), dim3(256), 0, s, am, A, voxel_scale, out);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }

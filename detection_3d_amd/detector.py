@@ -100,6 +100,7 @@ def build_backbone(cfg):
                        bn_momentum=cfg.SOLVER.BN_MOMENTUM, track_running_stats=cfg.SOLVER.TRACK_RUNNING_STATS)
 
 
+_ANCHORS_ONE_LAUNCH = os.environ.get("D3D_ANCHOR_LAUNCHES", "one") != "per-map"
 _FUSED_RPN_HEAD = os.environ.get("D3D_RPN_HEAD", "fused") != "gemm"     # "gemm": the library-GEMM form, for A/B runs
 
 
@@ -143,6 +144,20 @@ class AnchorGenerator(nn.Module):
                                              floats([float(v) for v in st.tolist()]))
                                             for b, st in zip(self.cell_anchors, self.strides)]
         stream = stream_of()
+        maps = feature_maps_sparse
+        if (_ANCHORS_ONE_LAUNCH and 1 <= len(maps) <= 6 and A <= 4 and all(c[1] == A for c in consts[:len(maps)])
+                and len(consts) >= len(maps) and all(f.metadata is maps[0].metadata for f in maps)):
+            packed = getattr(self, "_anchor_consts_maps", None)
+            if packed is None or packed[0] != len(maps):
+                from ._lib import floats
+                packed = self._anchor_consts_maps = (
+                    len(maps),
+                    floats([float(v) for b in self.cell_anchors[:len(maps)] for row in b.tolist() for v in row]),
+                    floats([float(v) for st in self.strides[:len(maps)].tolist() for v in st]))
+            sizes = _ints(tuple(int(v) for f in maps for v in scn.SCN._size3(f.spatial_size)))
+            check(lib().d3d_anchors_maps(maps[0].metadata._h, len(maps), sizes, packed[1], A, packed[2],
+                                         float(self.voxel_scale), ptr(out), stream))
+            return out
         for (base, n_base, stride), fmap, n in zip(consts, feature_maps_sparse, ns):
             if n:
                 check(lib().d3d_anchors(fmap.metadata._h, _ints(scn.SCN._size3(fmap.spatial_size)), base, n_base,
@@ -554,8 +569,10 @@ class FPN2MLPFeatureExtractor(nn.Module):
         y = torch.addmm(conv.bias, pooled.view(K * ph * pw, C * pz), conv.weight.view(conv.out_channels, C * pz).t())
         rep = y.shape[1]
         out, sm, si = y.new_empty(0), y.new_empty(rep), y.new_empty(rep)
-        SCN.BatchNormalization_updateOutput(y, out, sm, si, y.new_zeros(rep), y.new_ones(rep), bn.weight, bn.bias,
-                                            bn.eps, 0.0, True, 0.0)
+        run = getattr(self, "_bn_running", None)      # throw-away running statistics (momentum 0: overwritten per call)
+        if run is None or run[0].device != y.device or run[0].shape[0] != rep:
+            run = self._bn_running = (y.new_zeros(rep), y.new_ones(rep))
+        SCN.BatchNormalization_updateOutput(y, out, sm, si, run[0], run[1], bn.weight, bn.bias, bn.eps, 0.0, True, 0.0)
         h = torch.addmm(self.fc6.bias, out.view(K, ph * pw * rep), self._fc6_rows_weight(ph * pw).t())
         h = F.relu(self.fc7(F.relu(h)))
         mark("box features")

@@ -124,6 +124,11 @@ int d3d_get_spatial_locations(d3d_meta *m, const int *spatial_size_host, int64_t
  * + base[a], fp32 with the reference's operation order.  base_host [A,7], stride_host [3]; out [n_active*A, 7]. */
 int d3d_anchors(d3d_meta *m, const int *spatial_size_host, const float *base_host, int A,
                 const float *stride_host, float voxel_scale, float *out, void *stream);
+/* ... for all selected maps in one launch (the concatenation of AnchorGenerator.forward's list, rpn_sparse3d.py:246):
+ * sizes_host [n_maps*3], bases_host [n_maps, A, 7], strides_host [n_maps*3]; n_maps <= 6, A <= 4;
+ * out [sum_m n_active_m * A, 7], map after map.  Bit-identical to d3d_anchors per map.                              */
+int d3d_anchors_maps(d3d_meta *m, int n_maps, const int *sizes_host, const float *bases_host, int A,
+                     const float *strides_host, float voxel_scale, float *out, void *stream);
 
 /* a12. RPN head at inference, SingleConvRPNHead_Sparse3D.forward + cat_scales_obj_reg
  * (modeling/rpn/rpn_sparse3d.py:80-131 and :19-77) for all selected maps in ONE launch:
@@ -420,6 +425,10 @@ int d3d_post_select(const int32_t *keep, const int32_t *n_keep, int segments, in
 /* a14. BoxCoder3D.decode (maskrcnn_benchmark/modeling/box_coder_3d.py:38-65). */
 int d3d_box_decode(const float *enc, const float *anchors, int n, const float *weights_host,
                    float clip, float *out, void *stream);
+/* ... of class-wise encodings (roi_heads/box_head_3d/inference.py:84-87 `box_coder.decode(box_regression.view(sum, -1),
+ * concat_boxes)`): enc [n, 7 nc], anchors [n, 7] -> out [n, 7 nc], every class of row i decoded against anchor i. */
+int d3d_box_decode_classes(const float *enc, const float *anchors, int n, int nc, const float *weights_host,
+                           float clip, float *out, void *stream);
 /* ... of the rows the RPN's top-k selected (rpn/inference_3d.py:109-123: `box_regression[topk_idx]`,
  * `concat_anchors[topk_idx]`, then decode): out[i] = decode(enc[rows[i]], anchors[rows[i]]), rows int64 [n] on the device. */
 int d3d_box_decode_rows(const float *enc, const float *anchors, const int64_t *rows, int n,
