@@ -251,3 +251,38 @@ def test_roi_prepare_equals_the_host_side_chain_bit_for_bit(dev):
         else:
             assert got_levels is None
     assert roi_prepare(b[:0], 50.0, [0.25, 0.125], 8.0)[0].shape == (0, 8)
+
+
+def test_decode_of_selected_rows_and_padded_survivor_list(dev):
+    """d3d_box_decode_rows == decode of the gathered rows (oracle, bit-exact; rpn/inference_3d.py:109-123) and
+    d3d_gather_kept == boxes[keep[:n]] with clamped sizes, padded with candidate 0, the count stored to a pinned word
+    (rpn/inference_3d.py:127-131 + BoxList3D.clamp_size); empty and full survivor lists included."""
+    from detection_3d_amd import box_ops
+    from detection_3d_amd._lib import host_word
+    rng = np.random.RandomState(5)
+    n = 5000
+    anchors = np.concatenate([rng.rand(n, 3) * 20, 0.2 + rng.rand(n, 3) * 3, (rng.rand(n, 1) - 0.5) * 3], 1).astype(np.float32)
+    enc = (rng.randn(n, 7) * 0.3).astype(np.float32)
+    rows = rng.permutation(n)[:2000].astype(np.int64)
+    got = box_ops.box_decode_rows(torch.from_numpy(enc).to(dev), torch.from_numpy(anchors).to(dev),
+                                  torch.from_numpy(rows).to(dev))
+    assert np.array_equal(got.cpu().numpy(), oracle.box_decode(enc[rows], anchors[rows]))
+    boxes = got.clone()
+    boxes[::7, 3] = 0.0002                                       # sizes below the clamp
+    boxes[3::11, 5] = -1.0
+    scores = torch.from_numpy(rng.rand(2000).astype(np.float32)).to(dev)
+    keep = torch.from_numpy(rng.permutation(2000).astype(np.int32)).to(dev)
+    word, stored = host_word(dev, "test")
+    for nk in (0, 1, 617, 1000):
+        cnt = torch.tensor([nk], dtype=torch.int32, device=dev)
+        word[0] = -5
+        ob, os_ = box_ops.gather_kept(boxes, scores, keep, cnt, 1000, 0.001, count_host=word)
+        stored.record()
+        stored.synchronize()
+        assert int(word[0]) == nk
+        want = boxes[keep[:nk].long()].clone()
+        want[:, 3:6] = torch.clamp(want[:, 3:6], min=0.001)
+        assert torch.equal(ob[:nk], want) and torch.equal(os_[:nk], scores[keep[:nk].long()])
+        pad = boxes[0].clone()
+        pad[3:6] = torch.clamp(pad[3:6], min=0.001)
+        assert bool((ob[nk:] == pad).all()) and bool((os_[nk:] == scores[0]).all())

@@ -386,3 +386,16 @@ def test_pooler_one_launch_for_all_levels(setup, dev, monkeypatch):
     n = int(cnt.item())
     assert torch.equal(got[True][1][:n], got[True][0][:n]) and bool((got[True][1][n:] == -7.0).all())
     assert float(got[True][0].abs().max()) > 0
+
+
+def test_anchors_of_all_maps_in_one_launch(setup, monkeypatch):
+    """d3d_anchors_maps against one d3d_anchors launch per map and against the oracle's anchors: identical to the bit."""
+    from detection_3d_amd import detector
+    cfg, model, orc, result, mid = setup
+    gen = model.rpn.anchor_generator
+    got = {}
+    for one in (True, False):
+        monkeypatch.setattr(detector, "_ANCHORS_ONE_LAUNCH", one)
+        got[one] = gen.forward_cat(mid["rpn_features"]).cpu().numpy()
+    want = orc.anchors([f.get_spatial_locations().cpu().numpy() for f in mid["rpn_features"]])
+    assert np.array_equal(got[True], got[False]) and np.array_equal(got[True], want)
