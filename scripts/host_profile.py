@@ -30,3 +30,5 @@ run(20)
 pr.disable()
 st = pstats.Stats(pr)
 st.sort_stats("tottime").print_stats(45)
+# the detector tail alone: cumulative time of its Python functions and of the tensor-library calls under them
+st.sort_stats("cumtime").print_stats(r"detector\.py|box_ops\.py|roi_align_rotated_3d\.py|topk|sigmoid|addmm|linear|softmax|'sort'|'item'|synchronize|record", 40)
