@@ -414,12 +414,22 @@ def stats_from_partials(partials, partial_rows, rows, eps, want_invstd=True):
     planes = partials.shape[1] // 2
     mean = torch.empty(planes, dtype=torch.float32, device=partials.device)
     other = torch.empty_like(mean)
-    nbytes = lib().d3d_bn_scratch_bytes(planes)
+    nbytes = _bn_scratch_bytes(planes)
     scratch = _bn_scratch(partials.device, nbytes)
     check(lib().d3d_bn_stats_from_partials(ptr(partials), int(partial_rows), int(rows), planes, float(eps),
                                            int(bool(want_invstd)), ptr(mean), ptr(other), ptr(scratch), scratch.numel(),
                                            stream_of()))
     return mean, other
+
+
+_BN_SCRATCH_BYTES = {}
+
+
+def _bn_scratch_bytes(planes):
+    n = _BN_SCRATCH_BYTES.get(planes)
+    if n is None:
+        n = _BN_SCRATCH_BYTES[planes] = int(lib().d3d_bn_scratch_bytes(planes))
+    return n
 
 
 def batch_mean_invstd(features, eps):
@@ -429,7 +439,7 @@ def batch_mean_invstd(features, eps):
     rows, planes = features.shape
     mean = torch.empty(planes, dtype=torch.float32, device=features.device)
     invstd = torch.empty_like(mean)
-    nbytes = lib().d3d_bn_scratch_bytes(planes)
+    nbytes = _bn_scratch_bytes(planes)
     scratch = _bn_scratch(features.device, nbytes)
     check(lib().d3d_bn_batch_invstd_dt(ptr(features), rows, planes, float(eps), ptr(mean), ptr(invstd), ptr(scratch),
                                        scratch.numel(), dtype_code(features), stream_of()))
@@ -559,7 +569,7 @@ def BatchNormalization_updateOutput(input_features, output_features, saveMean, s
     output_features.resize_(rows, planes)
     w = weight if (weight is not None and weight.numel()) else None
     b = bias if (bias is not None and bias.numel()) else None
-    nbytes = lib().d3d_bn_scratch_bytes(planes)
+    nbytes = _bn_scratch_bytes(planes)
     scratch = _bn_scratch(input_features.device, nbytes)
     check(lib().d3d_bn_forward(ptr(input_features), ptr(output_features), rows, planes, ptr(saveMean),
                                ptr(saveInvStd), ptr(runningMean), ptr(runningVar), ptr(w), ptr(b),
@@ -573,7 +583,7 @@ def batch_stats(features):
     rows, planes = features.shape
     mean = torch.empty(planes, dtype=torch.float32, device=features.device)
     var = torch.empty_like(mean)
-    nbytes = lib().d3d_bn_scratch_bytes(planes)
+    nbytes = _bn_scratch_bytes(planes)
     scratch = _bn_scratch(features.device, nbytes)
     check(lib().d3d_bn_batch_stats(ptr(features), rows, planes, ptr(mean), ptr(var), ptr(scratch),
                                    scratch.numel(), stream_of()))

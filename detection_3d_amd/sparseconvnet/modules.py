@@ -308,13 +308,24 @@ class Convolution(Module, _PackedWeightMixin):
     def forward(self, input):
         feats, bn = _conv_input(input)
         assert feats.nelement() == 0 or feats.size(1) == SCN.stored_planes(self.nIn, feats.dtype)
-        out_size = (input.spatial_size - self.filter_size) // self.filter_stride + 1
-        assert ((out_size - 1) * self.filter_stride + self.filter_size == input.spatial_size).all(), \
-            (input.spatial_size, out_size, self.filter_size, self.filter_stride)
+        out_size = self._out_size(input.spatial_size)
         stats = _want_col_stats(feats)
         f = _apply(_ConvFn, feats, self.weight, None, 1, input.metadata, input.spatial_size, out_size,
                           self.filter_size, self.filter_stride, self._packed(feats.dtype), bn, stats)
         return _conv_output(f, stats, input.metadata, out_size)
+
+    def _out_size(self, in_size):
+        """(in - filter) // stride + 1, checked to tile the input exactly; remembered per input size (a pass asks for
+        the same few sizes every time, and each LongTensor operation costs the launch thread 2-3 us)"""
+        key = SCN._size3(in_size)
+        cache = self.__dict__.setdefault("_out_sizes", {})
+        out = cache.get(key)
+        if out is None:
+            out = (in_size - self.filter_size) // self.filter_stride + 1
+            assert ((out - 1) * self.filter_stride + self.filter_size == in_size).all(), \
+                (in_size, out, self.filter_size, self.filter_stride)
+            cache[key] = out
+        return out
 
     def input_spatial_size(self, out_size):
         return (out_size - 1) * self.filter_stride + self.filter_size
@@ -336,7 +347,11 @@ class Deconvolution(Module, _PackedWeightMixin):
     def forward(self, input, residual=None):
         feats, bn = _conv_input(input)
         assert feats.nelement() == 0 or feats.size(1) == SCN.stored_planes(self.nIn, feats.dtype)
-        out_size = (input.spatial_size - 1) * self.filter_stride + self.filter_size
+        key = SCN._size3(input.spatial_size)
+        cache = self.__dict__.setdefault("_out_sizes", {})
+        out_size = cache.get(key)
+        if out_size is None:         # remembered per input size: three LongTensor operations per call otherwise
+            out_size = cache[key] = (input.spatial_size - 1) * self.filter_stride + self.filter_size
         stats = _want_col_stats(feats)
         f = _apply(_ConvFn, feats, self.weight, None if residual is None else residual.features, 2,
                           input.metadata, input.spatial_size, out_size, self.filter_size, self.filter_stride,
