@@ -1320,6 +1320,36 @@ size_t d3d_voxelize_scratch_bytes(int n) {
   size_t nb = ((size_t)n + kScanTile - 1) / kScanTile;
   return 256 * 4 + (size_t)n * 8 + nb * 4 + 4096;
 }
+namespace d3d {
+__global__ void k_store_word(const int32_t *__restrict__ src, int32_t *__restrict__ dst) {
+  __hip_atomic_store(dst, *src, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// per host thread and device: a pinned word a kernel stores a count to and the event recorded behind that store
+struct VoxWord {
+  int32_t *word = nullptr;
+  hipEvent_t ev = nullptr;
+};
+static VoxWord *vox_word() {
+  static thread_local VoxWord words[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
+    set_error("d3d_voxelize: no current device");
+    return nullptr;
+  }
+  VoxWord &w = words[dev];
+  if (!w.word) {
+    hipError_t e = hipHostMalloc((void **)&w.word, 64, hipHostMallocPortable);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&w.ev, hipEventDisableTiming);
+    if (e != hipSuccess) {
+      set_error("d3d_voxelize: pinned word / event: %s", hipGetErrorString(e));
+      w.word = nullptr;
+      return nullptr;
+    }
+  }
+  return &w;
+}
+}  // namespace d3d
+
 int d3d_voxelize(const float *pcl, int n, int nfeat, double scale, const int *full, int64_t *coords,
                  float *feats, int *n_kept_host, void *scratch, size_t scratch_bytes, void *stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -1338,12 +1368,16 @@ int d3d_voxelize(const float *pcl, int n, int nfeat, double scale, const int *fu
   hipLaunchKernelGGL(k_vox_flag, grid1d(n), dim3(256), 0, s, pcl, n, nfeat, scale, mins, full[0], full[1], full[2], flag);
   int rc = scan_exclusive_i32(flag, rank, n, (int32_t *)(mins + 3), A, s);
   if (rc) return rc;
+  // the count goes to a pinned word by a store of its own launch, with an event behind it: the host waits for that
+  // event while k_vox_write runs (a pageable hipMemcpy + stream synchronise took the write's time and a staged copy more)
+  VoxWord *w = vox_word();
+  if (!w) return D3D_ERR_HIP;
+  hipLaunchKernelGGL(k_store_word, dim3(1), dim3(1), 0, s, (const int32_t *)(mins + 3), w->word);
+  D3D_HIP_CHECK(hipEventRecord(w->ev, s));
   hipLaunchKernelGGL(k_vox_write, grid1d(n), dim3(256), 0, s, pcl, n, nfeat, scale, mins, flag, rank, coords, feats);
   D3D_LAUNCH_CHECK();
-  int32_t total = 0;
-  D3D_HIP_CHECK(hipMemcpyAsync(&total, mins + 3, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  D3D_HIP_CHECK(hipStreamSynchronize(s));
-  *n_kept_host = total;
+  D3D_HIP_CHECK(hipEventSynchronize(w->ev));
+  *n_kept_host = *(volatile int32_t *)w->word;
   return D3D_OK;
 }
 
