@@ -27,12 +27,21 @@ def enable():
         return False
     if os.environ.get("PYTORCH_TUNABLEOP_ENABLED"):      # the user drives TunableOp: leave it alone
         return False
-    import torch.cuda.tunable as tunable
-    # TunableOp may rewrite its result file when the process exits: give it a private copy, never the tracked table
-    work = os.path.join(tempfile.mkdtemp(prefix="d3d_gemm_"), "gemm.csv")
-    shutil.copyfile(TABLE, work)
-    tunable.enable(True)
-    tunable.tuning_enable(False)
-    tunable.set_filename(work)
-    _state["on"] = bool(tunable.read_file(work))
+    try:
+        import torch.cuda.tunable as tunable
+        # TunableOp may rewrite its result file when the process exits: give it a private copy, never the tracked table
+        work = os.path.join(tempfile.mkdtemp(prefix="d3d_gemm_"), "gemm.csv")
+        shutil.copyfile(TABLE, work)
+        tunable.enable(True)
+        tunable.tuning_enable(False)
+        tunable.set_filename(work)
+        _state["on"] = bool(tunable.read_file(work))
+    except Exception as e:      # noqa: BLE001 -- an optional speed-up must never keep the model from being built
+        import warnings
+        warnings.warn("tuned GEMM table not used: %r (the library's default solutions run)" % (e,))
+        try:
+            tunable.enable(False)
+        except Exception:       # noqa: BLE001
+            pass
+        _state["on"] = False
     return _state["on"]
