@@ -244,17 +244,24 @@ def require_gpu(*tensors):
 
 
 _HOST_WORDS = {}
+_HOST_WORD_RING = 8
 _HOST_WORD_BLOCKING = os.environ.get("D3D_COUNT_EVENT_BLOCKING", "1") != "0"
 
 
 def host_word(device, tag):
-    """-> (pinned int32 [1] host tensor, event) of (device, current stream, tag), made once.  A kernel stores a count to
-    the word (pinned host memory is device-visible at the same address), the caller records the event behind that
-    launch and the host waits for the event alone: no copy engine between the kernel and the host, and launches
-    enqueued behind the event do not hold the host up."""
+    """-> (pinned int32 [1] host tensor, event): the next slot of a small ring kept per (device, current stream, tag), so
+    that a deferred read-back (PaddedProposals.resolve) still finds its own word and event when further counts have been
+    requested on the same stream meanwhile (up to _HOST_WORD_RING outstanding ones).  A kernel stores a count to the word
+    (pinned host memory is device-visible at the same address), the caller records the event behind that launch and
+    the host waits for the event alone: no copy engine between the kernel and the host, and launches enqueued behind the
+    event do not hold the host up."""
     key = (device.index, raw_stream(device), tag)
-    w = _HOST_WORDS.get(key)
-    if w is None:
-        w = _HOST_WORDS[key] = (torch.zeros(1, dtype=torch.int32).pin_memory(),
-                                torch.cuda.Event(blocking=_HOST_WORD_BLOCKING))
-    return w
+    ring = _HOST_WORDS.get(key)
+    if ring is None:
+        ring = _HOST_WORDS[key] = [[], 0]
+    slots, nxt = ring
+    if len(slots) < _HOST_WORD_RING:
+        slots.append((torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event(blocking=_HOST_WORD_BLOCKING)))
+        return slots[-1]
+    ring[1] = (nxt + 1) % _HOST_WORD_RING
+    return slots[nxt]

@@ -802,7 +802,8 @@ __global__ __launch_bounds__(kSelThreads) void k_post_select(const int32_t *__re
   __syncthreads();
   uint32_t pos = incl - mine;
   for (int w = 0; w < wave; w++) pos += wsum[w];
-  if (tid == kSelThreads - 1) *out_n = (int32_t)(pos + mine);
+  if (tid == kSelThreads - 1)   // out_n may be a pinned host word: system-scope release, like k_gather_kept's count
+    __hip_atomic_store(out_n, (int32_t)(pos + mine), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   for (int t = t0; t < t1; t++) {
     if (key[t] < thresh_key) continue;
     const int f = keep[t];

@@ -927,7 +927,8 @@ class SparseRCNN(nn.Module):
             mark("detections")
             if return_intermediates:
                 return result, {"rpn_features": rpn_features, "roi_features": roi_features,
-                                "proposals": proposals, "objectness": objectness, "example_id": None}
+                                "proposals": proposals, "objectness": objectness, "example_id": None,
+                                "sep_id": None}
             return result
         proposals, objectness = out[0].clone(), out[1]
         example_id = None
@@ -940,7 +941,8 @@ class SparseRCNN(nn.Module):
         mark("detections")
         if return_intermediates:
             return result, {"rpn_features": rpn_features, "roi_features": roi_features,
-                            "proposals": proposals, "objectness": objectness, "example_id": example_id}
+                            "proposals": proposals, "objectness": objectness, "example_id": example_id,
+                            "sep_id": sep_id}
         return result
 
 

@@ -14,7 +14,7 @@ import torch
 import torch.distributed as dist
 
 from . import training as T
-from .distributed import gather_detections, pack_detections
+from .distributed import agree_capacity, gather_detections, pack_detections
 from .scene_io import ScenePrefetcher
 
 
@@ -39,24 +39,24 @@ def inference(model, cfg, files, device, depth=2, max_det=None, voxelize_fn=_hip
                           depth=depth)
     was_training = model.training
     model.eval()
-    local, local_gt = [], []
+    results, truths = [], []
     with torch.no_grad():
         for i, (pcl, tg, _path) in enumerate(pre):
-            scene_id = rank + i * world
             coords, feats = voxelize_fn(pcl, cfg)
-            res = model([coords, feats])
-            local.append(pack_detections(scene_id, res, max_det))
-            gt = {"bbox3d": tg["bbox3d"], "scores": torch.ones(tg["bbox3d"].shape[0], device=tg["bbox3d"].device),
-                  "labels": tg["labels"]}
-            local_gt.append(pack_detections(scene_id, gt, max_det))
+            results.append((rank + i * world, model([coords, feats])))
+            truths.append({"bbox3d": tg["bbox3d"], "labels": tg["labels"],
+                           "scores": torch.ones(tg["bbox3d"].shape[0], device=tg["bbox3d"].device)})
     model.train(was_training)
+    # capacities from the data (one MAX all-reduce each): a building with more ground-truth boxes -- or, with ties at the
+    # cut, more detections -- than DETECTIONS_PER_IMG x groups keeps all of them
+    cap_det = agree_capacity([r["bbox3d"].shape[0] for _, r in results], max_det, device)
+    cap_gt = agree_capacity([t["bbox3d"].shape[0] for t in truths], 1, device)
+    local = [pack_detections(sid, r, cap_det) for sid, r in results]
+    local_gt = [pack_detections(sid, t, cap_gt) for (sid, _), t in zip(results, truths)]
     n = len(files)
-    if not local:      # a rank without buildings still takes part in the gather
-        dets = gather_detections([], n, max_det) if world > 1 else {}
-        gts = gather_detections([], n, max_det) if world > 1 else {}
-    else:
-        dets = gather_detections(local, n, max_det)
-        gts = gather_detections(local_gt, n, max_det)
+    # a rank without buildings still takes part in the gathers, with an empty contribution on ITS device
+    dets = gather_detections(local, n, cap_det, device=device)
+    gts = gather_detections(local_gt, n, cap_gt, device=device)
     if rank != 0:
         return None
     return dets, {k: {"bbox3d": v["bbox3d"], "labels": v["labels"]} for k, v in gts.items()}

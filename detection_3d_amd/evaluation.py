@@ -67,8 +67,7 @@ def calc_prec_rec(preds, gts, iou_thresh, eval_aug_thickness, iou_fn=_gpu_iou):
         prec[l] = tp / (fp + tp)
         with np.errstate(divide="ignore", invalid="ignore"):
             rec[l] = tp / n_pos[l]
-    calc_prec_rec.last_per_building = dict(per_building)
-    return prec, rec, scores, pious
+    return prec, rec, scores, pious, dict(per_building)
 
 
 def cal_mious(predious_per_building, iou_thresh, n_cls):
@@ -129,12 +128,12 @@ def eval_detection_suncg(preds, gts, cfg, use_07_metric=True, iou_fn=_gpu_iou):
     TEST.EVAL_AUG_THICKNESS_* (maskrcnn_benchmark/config/defaults.py:318-320)."""
     ay, az = cfg.TEST.EVAL_AUG_THICKNESS_Y_TAR_ANC, cfg.TEST.EVAL_AUG_THICKNESS_Z_TAR_ANC
     aug = {'target_Y': ay[0], 'anchor_Y': ay[1], 'target_Z': az[0], 'anchor_Z': az[1]}
-    prec, rec, scores, pious = calc_prec_rec(preds, gts, cfg.TEST.IOU_THRESHOLD, aug, iou_fn)
+    prec, rec, scores, pious, per_building = calc_prec_rec(preds, gts, cfg.TEST.IOU_THRESHOLD, aug, iou_fn)
     ap, table = calc_ap(prec, rec, use_07_metric, scores, pious)
     # the IoU row the reference prints under AP (performance_str, suncg_eval.py:217,306: the table averaged over its 11
     # recall steps, IoU column) -- the README's AIoU line; index 0 = mean over the classes like `ap`
     with np.errstate(all="ignore"):
         aiou = np.nanmean(table[:, :, 3], axis=1)
-    mious = cal_mious(calc_prec_rec.last_per_building, cfg.TEST.IOU_THRESHOLD, len(prec))
+    mious = cal_mious(per_building, cfg.TEST.IOU_THRESHOLD, len(prec))
     return {"ap": ap, "map": float(np.nanmean(ap[1:])), "prec": prec, "rec": rec, "aiou": aiou, "mious": mious,
             "recall_precision_score_iou": table}   # [n_cls, 11, 4]

@@ -6,7 +6,9 @@ run at 80 / 98 TFLOP/s for these shapes, the best ones it holds reach 101 / 145.
 file of one tuning run on an MI355X (`scripts/tune_gemms.sh`; the validator lines pin torch, ROCm, hipBLASLt / rocBLAS
 builds and the architecture -- on any mismatch TunableOp ignores the file and the default solutions run).  Shapes that
 are not in the file (another proposal count, another config) take the default path; nothing is tuned at run time.
-D3D_TUNED_GEMMS=0 switches it off."""
+D3D_TUNED_GEMMS=0 switches it off.  Process-wide side effect: TunableOp is a torch-global switch, so while the table is
+loaded EVERY GEMM of the host process consults it (shapes outside the table run the default solutions, as before); when
+the table does not load, TunableOp is switched off again."""
 import os
 import shutil
 import tempfile
@@ -30,12 +32,17 @@ def enable():
     try:
         import torch.cuda.tunable as tunable
         # TunableOp may rewrite its result file when the process exits: give it a private copy, never the tracked table
-        work = os.path.join(tempfile.mkdtemp(prefix="d3d_gemm_"), "gemm.csv")
+        workdir = tempfile.mkdtemp(prefix="d3d_gemm_")
+        import atexit
+        atexit.register(shutil.rmtree, workdir, True)
+        work = os.path.join(workdir, "gemm.csv")
         shutil.copyfile(TABLE, work)
         tunable.enable(True)
         tunable.tuning_enable(False)
         tunable.set_filename(work)
         _state["on"] = bool(tunable.read_file(work))
+        if not _state["on"]:            # validators did not match this build: leave TunableOp as we found it (off)
+            tunable.enable(False)
     except Exception as e:      # noqa: BLE001 -- an optional speed-up must never keep the model from being built
         import warnings
         warnings.warn("tuned GEMM table not used: %r (the library's default solutions run)" % (e,))

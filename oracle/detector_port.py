@@ -11,6 +11,15 @@ from . import (bn_forward, box_decode, conv_rules, input_forward, input_sites, n
                rotate_nms_3d, rule_conv, sparse_to_dense, subm_nbr)
 
 
+def roi_levels(boxes_pixels, scales, canonical_size):
+    """LevelMapper_3d (modeling/poolers_3d.py:57-69): argmin over the pooler scales of |scale - sqrt(max(dy, dx)) / canonical|
+    on boxes already in pixels.  -> int64 [K]"""
+    p = np.asarray(boxes_pixels, np.float32)
+    size = np.sqrt(p[:, 3:5].max(1))
+    dif = np.abs(np.asarray(scales, np.float32)[None] - (size / np.float32(canonical_size))[:, None])
+    return dif.argmin(1)
+
+
 class OracleFPN:
     """FPN_Net forward (SparseConvNet/sparseconvnet/fpn_net.py:140-203), eval mode with
     track_running_stats=False: every BN normalises with the batch mean / unbiased variance
@@ -121,6 +130,79 @@ def rois_from_boxes(boxes_pixels):
     return rois.numpy()
 
 
+def class_groups(separate_classes_id, num_input_classes):
+    """SeperateClassifier.__init__ (modeling/seperate_classifier.py:23-44): group 0 = the classes that were not separated
+    (real background column 0 first); separated group g >= 1 = [its own background column num_input_classes + g - 1] +
+    its sorted classes.  -> list of column lists (empty separate_classes_id: one group of every column)."""
+    groups = [sorted(int(c) for c in g) for g in separate_classes_id]
+    flat = [c for g in groups for c in g]
+    assert 0 not in flat
+    out = [[c for c in range(num_input_classes) if c not in flat]]
+    for i, g in enumerate(groups):
+        out.append([num_input_classes + i] + g)
+    return out
+
+
+def group_targets(grouped_classes, boxes, labels):
+    """seperate_targets_and_update_labels (seperate_classifier.py:236-287): per group the GT boxes of its classes, class by
+    class in the group's column order (one nonzero per class, concatenated), labels renumbered to the position inside
+    the group.  -> list of (boxes [m_g, 7], labels int64 [m_g])."""
+    boxes, labels = np.asarray(boxes, np.float32), np.asarray(labels, np.int64)
+    out = []
+    for classes in grouped_classes:
+        ids = [np.nonzero(labels == c)[0] for c in classes]
+        new = [np.full(len(i), k, np.int64) for k, i in enumerate(ids)]
+        ids, new = np.concatenate(ids), np.concatenate(new)
+        out.append((boxes[ids], new))
+    return out
+
+
+def matcher(q, high, low, allow_low_quality, yaw_diff=None, yaw_threshold=3.1416 * 0.4):
+    """Matcher.__call__ (modeling/matcher.py:58-177) in numpy: q fp32 [M gt, N] -> int64 [N] (gt index, -1 below the low
+    threshold, -2 between).  With yaw_diff the qualities of pairs whose yaws differ by >= yaw_threshold are zeroed
+    (:50-55); allow_low_quality: every gt keeps the predictions that tie its best quality (:131-147), and would-be
+    negatives within 0.05 of a gt's best (and above 0.02) become ignored (:149-158)."""
+    q = np.asarray(q, np.float32)
+    if yaw_diff is not None and not yaw_threshold > 1.58:
+        q = q * (np.abs(np.asarray(yaw_diff, np.float32)) < np.float32(yaw_threshold)).astype(np.float32)
+    vals, matches = q.max(0), q.argmax(0).astype(np.int64)          # ties: lowest gt index, as torch.max
+    all_matches = matches.copy()
+    below = vals < np.float32(low)
+    between = (vals >= np.float32(low)) & (vals < np.float32(high))
+    matches[below] = -1
+    matches[between] = -2
+    if allow_low_quality:
+        highest = q.max(1)
+        upd = np.nonzero(q == highest[:, None])[1]
+        matches[upd] = all_matches[upd]
+        thr = np.maximum(np.float32(0.02), highest - np.float32(0.05))
+        ignore = (q > thr[:, None]).any(0) & (matches == -1)
+        matches[ignore] = -2
+    return matches
+
+
+def rpn_labels(cfg, anchors, gt_boxes, return_iou=False):
+    """RPNLossComputation.match_targets_to_anchors + prepare_targets (modeling/rpn/loss_3d.py:88-109,178-205):
+    IoU criterion 2 with the label thickness clamps, |yaw difference| wrapped to [-pi/2, pi/2), Matcher with low-quality
+    matches -> labels fp32 [N]: 1 positive, 0 negative, -1 ignored."""
+    from . import boxes_iou_3d
+    rpn = cfg.MODEL.RPN
+    anchors, gt_boxes = np.asarray(anchors, np.float32), np.asarray(gt_boxes, np.float32)
+    if gt_boxes.shape[0] == 0:
+        lab = np.zeros(anchors.shape[0], np.float32)
+        return (lab, None) if return_iou else lab
+    ay, az = rpn.LABEL_AUG_THICKNESS_Y_TAR_ANC, rpn.LABEL_AUG_THICKNESS_Z_TAR_ANC
+    aug = dict(target_Y=ay[0], anchor_Y=ay[1], target_Z=az[0], anchor_Z=az[1])
+    q = boxes_iou_3d(gt_boxes, anchors, aug, criterion=2)
+    d = gt_boxes[:, 6:7] - anchors[None, :, 6]                                   # angle_dif(anchor, target, 0)
+    pi = np.float32(math.pi)
+    d = np.abs(d - np.floor(d / pi + np.float32(0.5)) * pi)
+    m = matcher(q, rpn.FG_IOU_THRESHOLD, rpn.BG_IOU_THRESHOLD, True, d, rpn.YAW_THRESHOLD)
+    lab = (m >= 0).astype(np.float32)
+    lab[m == -2] = -1
+    return (lab, (q, d, m)) if return_iou else lab
+
+
 class OracleDetector:
     """SparseRCNN inference (modeling/detector/sparse_rcnn.py:37-76) on the CPU."""
 
@@ -130,6 +212,9 @@ class OracleDetector:
         self.fpn = OracleFPN(sd, s.VOXEL_FULL_SCALE, len(s.nPlanesFront), cfg.MODEL.RPN.RPN_SCALES_FROM_TOP,
                              cfg.MODEL.ROI_BOX_HEAD.POOLER_SCALES_FROM_TOP, cfg.MODEL.RPN.RPN_3D_2D_SELECTOR,
                              prefix="backbone.")
+        # class groups (3G6c): [] -> one group of all columns
+        self.groups = class_groups(getattr(cfg.MODEL, "SEPARATE_CLASSES_ID", []), len(cfg.INPUT.CLASSES))
+        self.rpn_groups = (len(self.groups) - 1) * int(cfg.MODEL.SEPARATE_RPN) + 1
 
     def anchors(self, locs):
         rpn = self.cfg.MODEL.RPN
@@ -147,21 +232,54 @@ class OracleDetector:
             out.append((a + base[None]).reshape(-1, 7))
         return np.concatenate(out)
 
-    def rpn(self, rpn_maps):
-        rc = self.cfg.MODEL.RPN
+    def rpn_head(self, rpn_maps):
+        """RPNHead.forward + cat_scales_obj_reg (rpn/rpn_sparse3d.py:19-77,109-131): -> objectness [n A, G] (sigmoid not
+        applied), regression [n A, 7 G], anchors [n A, 7]; rows ordered scale, site, anchor; the head's A*G (A*7*G) output
+        channels of a site are read as [A, G] ([A, 7 G])."""
+        G = self.rpn_groups
         obj, reg = [], []
         for f, _ in rpn_maps:
             t = F.relu(_lin(self.sd, "rpn.head.conv", torch.from_numpy(f)))
-            obj.append(_lin(self.sd, "rpn.head.cls_logits", t).reshape(-1))
-            reg.append(_lin(self.sd, "rpn.head.bbox_pred", t).reshape(-1, 7))
-        scores = torch.cat(obj).sigmoid()
-        reg = torch.cat(reg)
-        anchors = self.anchors([l for _, l in rpn_maps])
+            obj.append(_lin(self.sd, "rpn.head.cls_logits", t).reshape(-1, G))
+            reg.append(_lin(self.sd, "rpn.head.bbox_pred", t).reshape(-1, 7 * G))
+        return torch.cat(obj), torch.cat(reg), self.anchors([l for _, l in rpn_maps])
+
+    def rpn_select(self, objectness, reg, anchors, topk_idx=None, scores=None):
+        """RPNPostProcessor.forward_for_single_feature_map (rpn/inference_3d.py:82-163) for one objectness column:
+        sigmoid, top-k, decode, boxlist_nms_3d.  topk_idx: positions to use instead of this side's own top-k (tests hand
+        in the device's choice when scores tie); scores: the sigmoid values to select on instead of this side's own
+        (libm's expf differs from the device's in the last bit, which reorders near-ties).  -> (proposals, scores, kept positions in the top-k list, top-k idx)"""
+        rc = self.cfg.MODEL.RPN
+        if scores is None:
+            scores = objectness.sigmoid()
+        scores = torch.as_tensor(scores)
         k = min(rc.FPN_PRE_NMS_TOP_N_TEST, scores.shape[0])
-        sk, idx = scores.topk(k, sorted=True)
+        if topk_idx is None:
+            # inference_3d.py:109 `topk(sorted=True)`: torch leaves the order among equal scores open (sigmoid saturates to
+            # exactly 1.0 for large logits); defined here as descending score, lower index first (= the stable argsort of
+            # nms_cpu.py:37's -scores), which d3d_rotate_nms_3d / d3d_topk follow
+            idx = torch.from_numpy(np.argsort(-scores.numpy().astype(np.float64), kind="stable")[:k].copy())
+            sk = scores[idx]
+        else:
+            idx = torch.as_tensor(topk_idx, dtype=torch.int64)
+            sk = scores[idx]
         props = box_decode(reg[idx].numpy(), anchors[idx.numpy()])
         keep = nms_clamped(props, sk.numpy(), rc.NMS_THRESH, rc.NMS_AUG_THICKNESS_Y_Z, rc.FPN_POST_NMS_TOP_N_TEST)
-        return props[keep], sk.numpy()[keep]
+        return props[keep], sk.numpy()[keep], keep, idx.numpy()
+
+    def rpn(self, rpn_maps):
+        obj, reg, anchors = self.rpn_head(rpn_maps)
+        assert obj.shape[1] == 1
+        p, sc, _, _ = self.rpn_select(obj[:, 0], reg, anchors)
+        return p, sc
+
+    def rpn_grouped(self, rpn_maps):
+        """seperate_rpn_selector (seperate_classifier.py:58-81): the selector once per class group on the group's
+        objectness column and 7 regression columns (budgets already scaled by 1.5 / groups, tools/train_net_sparse3d.py:
+        247-255).  -> list over groups of (proposals, scores)"""
+        obj, reg, anchors = self.rpn_head(rpn_maps)
+        assert obj.shape[1] == len(self.groups)
+        return [self.rpn_select(obj[:, g], reg[:, 7 * g:7 * g + 7], anchors)[:2] for g in range(obj.shape[1])]
 
     def pool(self, roi_maps, proposals, batch_ids=None, n_examples=1):
         """batch_ids [K]: example of every proposal (poolers_3d.py:112-118 writes it into column 0 of the RoI)."""
@@ -171,9 +289,7 @@ class OracleDetector:
         rois = rois_from_boxes(p)
         if batch_ids is not None:
             rois[:, 0] = np.asarray(batch_ids, np.float32)
-        size = np.sqrt(p[:, 3:5].max(1))
-        dif = np.abs(np.asarray(head.POOLER_SCALES_SPATIAL, np.float32)[None] - (size / np.float32(head.CANONICAL_SIZE))[:, None])
-        levels = dif.argmin(1)
+        levels = roi_levels(p, head.POOLER_SCALES_SPATIAL, head.CANONICAL_SIZE)
         ph, pw, pz = head.POOLER_RESOLUTION
         out = np.zeros((p.shape[0], roi_maps[0][0].shape[1], ph, pw, pz), np.float32)
         for lvl, (f, loc, size3) in enumerate(roi_maps):
@@ -220,8 +336,31 @@ class OracleDetector:
             b, s, l = b[k], s[k], l[k]
         return b, s, l
 
+    def post_grouped(self, logits, reg, proposals, sep_id):
+        """SeperateClassifier.post_processor (seperate_classifier.py:299-321): rows of group g restricted to the group's
+        class columns (:217-234), the plain post-processor per group (DETECTIONS_PER_IMG already scaled), labels mapped
+        back to the original class ids, groups concatenated in order.  -> (boxes, scores, labels)"""
+        sep_id = np.asarray(sep_id)
+        n = logits.shape[0]
+        ob, os_, ol = [], [], []
+        for g, cols in enumerate(self.groups):
+            ids = torch.from_numpy(np.nonzero(sep_id == g)[0])
+            c = torch.tensor(cols)
+            lg = logits[ids][:, c]
+            rg = reg.view(n, -1, 7)[:, c, :].reshape(n, -1)[ids]
+            b, sc, lab = self.post(lg, rg, np.asarray(proposals, np.float32)[ids.numpy()])
+            ob.append(b); os_.append(sc); ol.append(np.asarray(cols, np.int64)[lab])
+        return np.concatenate(ob), np.concatenate(os_), np.concatenate(ol)
+
     def __call__(self, coords, feats):
         rpn_maps, roi_maps = self.fpn(coords, feats)
+        if len(self.groups) > 1 and self.rpn_groups > 1:
+            per = self.rpn_grouped(rpn_maps)
+            props = np.concatenate([p for p, _ in per]).copy()
+            sep_id = np.concatenate([np.full(len(p), g, np.int64) for g, (p, _) in enumerate(per)])
+            props[:, 3:6] = np.maximum(props[:, 3:6], 0.001)
+            logits, reg = self.box_head(self.pool(roi_maps, props))
+            return self.post_grouped(logits, reg, props, sep_id)
         props, _ = self.rpn(rpn_maps)
         props = props.copy()
         props[:, 3:6] = np.maximum(props[:, 3:6], 0.001)

@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--scenes", type=int, default=0, help="synthetic scenes to write (default: 2 per rank)")
     ap.add_argument("--points", type=int, default=500_000)
     ap.add_argument("--log-every", type=int, default=0)
+    ap.add_argument("--verify", action="store_true",
+                    help="after the steps: compare the weights of all ranks and gather the detections of every scene")
     args = ap.parse_args()
     rank, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -66,6 +68,23 @@ def main():
     torch.manual_seed(0)                  # same initial weights on every rank (DDP also broadcasts rank 0's)
     model = build_detection_model(cfg).to(dev)
     out = engine.train(model, cfg, files, dev, args.steps, local_rank=local_rank, log_every=args.log_every)
+    if args.verify:
+        # (1) the averaged-gradient steps leave every rank with the same weights (fingerprint: sum and sum of squares of
+        # every parameter in fp64); (2) the sharded inference loop returns every scene's detections on rank 0
+        with torch.no_grad():
+            fp = torch.stack([torch.stack([p.detach().double().sum(), (p.detach().double() ** 2).sum()])
+                              for p in model.parameters()]).reshape(-1)
+        if dist.get_backend() == "gloo":
+            fp = fp.cpu()
+        fps = [torch.empty_like(fp) for _ in range(WORLD)]
+        dist.all_gather(fps, fp)
+        out["weights_equal"] = bool(all(torch.equal(fps[0], f) for f in fps))
+        res = engine.inference(model, cfg, files, dev)
+        if rank == 0:
+            dets, gts = res
+            out["scenes_gathered"] = sorted(int(k) for k in dets)
+            out["detections_per_scene"] = [int(dets[k]["bbox3d"].shape[0]) for k in sorted(dets)]
+            out["gt_per_scene"] = [int(gts[k]["bbox3d"].shape[0]) for k in sorted(gts)]
     if rank == 0:
         out.update(config=args.config, n_gpus=WORLD, points_per_building=args.points if not args.data else None,
                    unit="buildings/s", metric="training buildings/sec (forward + backward + SGD, DDP)")

@@ -32,3 +32,28 @@ def sort_by_loc(feats, loc):
     loc = np.asarray(loc)
     order = np.lexsort((loc[:, 2], loc[:, 1], loc[:, 0], loc[:, 3]))
     return feats[order], loc[order]
+
+
+def label_differences_sit_on_thresholds(lab_a, lab_b, q_a, q_b, low, high, eps=1e-6):
+    """Matcher labels from two IoU matrices q_a / q_b [M gt, N] (both already yaw-masked) may differ only where an IoU sits on
+    one of the Matcher's thresholds (modeling/matcher.py:84-100,131-158): the low / high thresholds on a column's
+    maximum, a gt's best quality (the ties that become low-quality matches) and its ignore threshold max(0.02,
+    best - 0.05).  -> (number of differing columns, list of unexplained column indices)."""
+    lab_a, lab_b = np.asarray(lab_a), np.asarray(lab_b)
+    diff = np.nonzero(lab_a != lab_b)[0]
+    bad = []
+    if not len(diff):
+        return 0, bad
+    q_a, q_b = np.asarray(q_a, np.float64), np.asarray(q_b, np.float64)
+    best = np.stack([q_a.max(1), q_b.max(1)])                                   # [2, M]
+    ign = np.maximum(0.02, best - 0.05)
+    for j in diff:
+        ok = False
+        for q in (q_a, q_b):
+            col = q[:, j]
+            m = col.max()
+            ok |= min(abs(m - low), abs(m - high)) <= eps
+            ok |= bool((np.abs(col[None] - best) <= eps).any()) or bool((np.abs(col[None] - ign) <= eps).any())
+        if not ok:
+            bad.append(int(j))
+    return len(diff), bad

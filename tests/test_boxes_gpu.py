@@ -245,6 +245,13 @@ def test_roi_prepare_equals_the_host_side_chain_bit_for_bit(dev):
         want_rois = convert_to_roi_format(p)
         got_rois, got_levels = roi_prepare(b, 50.0, scales, 8.0)
         assert torch.equal(got_rois, want_rois)
+        # and against the oracle port (poolers_3d.py:57-69,107-124 restated on the CPU): RoI rows and FPN levels, exact
+        from oracle.detector_port import roi_levels, rois_from_boxes
+        p_np = b.cpu().numpy().copy()
+        p_np[:, 0:6] *= np.float32(50.0)
+        assert np.array_equal(got_rois.cpu().numpy(), rois_from_boxes(p_np))
+        if len(scales) > 1:
+            assert np.array_equal(got_levels.cpu().numpy().astype(np.int64), roi_levels(p_np, scales, 8.0))
         if len(scales) > 1:
             assert torch.equal(got_levels.long(), pooler.map_levels(p))
             assert len(torch.unique(got_levels)) > 1

@@ -149,3 +149,50 @@ def test_engine_train_and_inference_world2_gloo(tmp_path):
     ok = q.get(timeout=180)
     [p.join(60) for p in procs]
     assert ok and all(p.exitcode == 0 for p in procs)
+
+
+def _one_file_worker(rank, world, port, files, q):
+    """one building for two ranks (rank 1 owns none and still joins the gathers with an empty contribution), and a
+    capacity (max_det 3) below both the detections (5) and the ground truth (22 boxes) of the building"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from detection_3d_amd import engine
+    from detection_3d_amd.config import get_cfg
+    cfg = get_cfg("4c_Fpn432")
+    model = _StandIn()
+    res = engine.inference(model, cfg, files, None, max_det=3, voxelize_fn=_cpu_voxelize)
+    if rank == 0:
+        dets, gts = res
+        ok = sorted(dets) == [0] and dets[0]["bbox3d"].shape == (5, 7) and gts[0]["bbox3d"].shape[0] == 22
+        q.put(bool(ok))
+    elif res is not None:
+        q.put(False)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_inference_keeps_every_box_and_serves_a_rank_without_buildings(tmp_path):
+    from detection_3d_amd.synthetic import write_scene_file
+    files = [write_scene_file(str(tmp_path / "only.npz"), 3, 2000)]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_one_file_worker, args=(r, 2, port, files, q)) for r in range(2)]
+    [p.start() for p in procs]
+    ok = q.get(timeout=180)
+    [p.join(60) for p in procs]
+    assert ok and all(p.exitcode == 0 for p in procs)
+
+
+def test_pack_detections_refuses_to_truncate():
+    import pytest
+    from detection_3d_amd.distributed import agree_capacity, pack_detections
+    r = _fake_result(0)
+    n = r["bbox3d"].shape[0]
+    with pytest.raises(ValueError):
+        pack_detections(0, r, n - 1)
+    assert agree_capacity([n, 1], 2) == n and agree_capacity([], 7) == 7
+    assert pack_detections(0, r, agree_capacity([n], 1)).shape == (n + 1, 9)

@@ -214,9 +214,9 @@ def test_6c_training_step_at_full_size(dev):
 
 def test_config5_bf16_batch_of_four_1m_point_buildings(dev):
     """BASELINE configs[4] at its stated size: bf16 sparse conv, ~1 M-point scenes (35 x 27 x 2.7 m), 4 examples per batch.
-    Integer results against the oracle at full size (site coordinates of every map handed on: exact); bf16 maps against the
-    fp32 pass of the same batch (5e-2 of the map's magnitude, the tolerance of tests/test_bf16_gpu.py for a chain of
-    layers); deterministic to the bit; every example yields detections."""
+    Against the batch-aware oracle port at full size: site coordinates of every map handed on exact, the fp32 pass 2e-4 and
+    the bf16 pass 5e-2 of each map's magnitude (the tolerance of tests/test_bf16_gpu.py for a chain of layers);
+    deterministic to the bit; every example yields detections."""
     from detection_3d_amd.config import get_cfg
     from detection_3d_amd.detector import build_detection_model
     from detection_3d_amd.synthetic import make_scene
@@ -256,11 +256,181 @@ def test_config5_bf16_batch_of_four_1m_point_buildings(dev):
     roi16 = mid16["roi_features"]                       # ups[4] = scale 4 (256 x 256 x 32), ups[3] = scale 5
     for t, want in zip(roi16, (locs[4], locs[5])):
         assert np.array_equal(t.get_spatial_locations().cpu().numpy(), want.astype(np.int64))
-    for a, b, c in zip(mid16["rpn_features"] + roi16, mid16b["rpn_features"] + mid16b["roi_features"],
-                       mid32["rpn_features"] + mid32["roi_features"]):
+    # every map handed on, against the batch-aware oracle port at full size (one backbone pass over the 4 examples, BatchNorm
+    # over all rows as the reference; ~30 s on the host): the fp32 pass at 2e-4 of the map's magnitude, the bf16 pass at the
+    # chain tolerance of tests/test_bf16_gpu.py (5e-2: one rounding to bf16 per layer, ~45 layers)
+    orc = OracleDetector(model.state_dict(), cfg)
+    rpn_w, roi_w = orc.fpn(np.concatenate(cref), feats.cpu().numpy())
+    want_maps = [(f, l) for f, l in rpn_w] + [(f, l) for f, l, _ in roi_w]
+    got16, got32 = mid16["rpn_features"] + roi16, mid32["rpn_features"] + mid32["roi_features"]
+    assert len(want_maps) == len(got16) == len(got32) == 6
+    for a, c, (wf, wl) in zip(got16, got32, want_maps):
+        wf, wl = sort_by_loc(wf, wl)
+        g32, l32 = sort_by_loc(c.features.cpu().numpy(), c.get_spatial_locations().cpu().numpy())
+        g16, l16 = sort_by_loc(a.features.cpu().numpy(), a.get_spatial_locations().cpu().numpy())
+        assert np.array_equal(l32, wl.astype(np.int64)) and np.array_equal(l16, l32)      # site sets incl. example index
+        assert rel_err(g32, wf) < 2e-4, (g32.shape, rel_err(g32, wf))
+        assert rel_err(g16, wf) < 5e-2, (g16.shape, rel_err(g16, wf))
+    for a, b, c in zip(got16, mid16b["rpn_features"] + mid16b["roi_features"], got32):
         assert torch.equal(a.features, b.features)                                   # deterministic to the bit
         assert a.features.dtype == torch.float32 and a.features.shape == c.features.shape
         assert rel_err(a.features.cpu().numpy(), c.features.cpu().numpy()) < 5e-2
     assert len(res16) == B and all(r["bbox3d"].shape[0] > 0 for r in res16) and all(r["bbox3d"].shape[0] > 0 for r in res32)
     for r, rb in zip(res16, res16b):
         assert torch.equal(r["bbox3d"], rb["bbox3d"]) and torch.equal(r["scores"], rb["scores"])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3]: 3G6c_Fpn4321 (three class groups) at 500 k points against the oracle port's grouped detector
+def _targets_3g(dev):
+    from detection_3d_amd.synthetic import make_targets
+    b, l = make_targets(5)
+    b, l = b.copy(), l.copy()
+    extra = np.array([[12.5, 9.5, 0.0, 19.0, 25.0, 0.1, 0.0], [12.5, 9.5, 2.6, 19.0, 25.0, 0.1, 0.0],      # floor, ceiling
+                      [6.0, 5.0, 0.0, 8.0, 6.0, 0.1, 0.0], [18.0, 13.0, 2.6, 8.0, 6.0, 0.1, 0.0]], np.float32)
+    b = np.concatenate([b, extra])
+    l = np.concatenate([l, np.array([5, 4, 5, 4], np.int64)])                  # suncg_metas order: ceiling 4, floor 5
+    return b, l, {"bbox3d": torch.from_numpy(b).to(dev), "labels": torch.from_numpy(l).to(dev)}
+
+
+@pytest.fixture(scope="module")
+def full3g(dev):
+    from detection_3d_amd.config import get_cfg
+    from detection_3d_amd.detector import build_detection_model
+    from detection_3d_amd.synthetic import make_scene
+    from detection_3d_amd.voxelize import voxelize
+    cfg = get_cfg("3G6c_Fpn4321")
+    torch.manual_seed(3)
+    model = build_detection_model(cfg).to(dev).eval()
+    _sharpen(model)
+    pcl = make_scene(5, N_POINTS)
+    with torch.no_grad():
+        coords, feats = voxelize(torch.from_numpy(pcl).to(dev), 50, cfg.SPARSE3D.VOXEL_FULL_SCALE)
+        result, mid = model([coords, feats], return_intermediates=True)
+    torch.cuda.synchronize()
+    c_ref, f_ref = oracle.voxelize(pcl, 50, cfg.SPARSE3D.VOXEL_FULL_SCALE)
+    assert np.array_equal(coords.cpu().numpy(), c_ref) and np.array_equal(feats.cpu().numpy(), f_ref)
+    orc = OracleDetector(model.state_dict(), cfg)
+    assert orc.groups == [[0, 2, 3], [6, 1], [7, 4, 5]]
+    rpn_w, roi_w = orc.fpn(c_ref, f_ref)
+    return cfg, model, orc, result, mid, rpn_w, roi_w, (coords, feats)
+
+
+def test_3g6c_backbone_maps_vs_oracle_at_full_size(full3g):
+    cfg, model, orc, result, mid, rpn_w, roi_w, _ = full3g
+    assert len(mid["rpn_features"]) == len(rpn_w) == 6 and len(mid["roi_features"]) == len(roi_w) == 2
+    pairs = list(zip(mid["rpn_features"], [(f, l) for f, l in rpn_w])) + \
+        list(zip(mid["roi_features"], [(f, l) for f, l, _ in roi_w]))
+    for got, (wf, wl) in pairs:
+        gf, gl = sort_by_loc(got.features.cpu().numpy(), got.get_spatial_locations().cpu().numpy())
+        wf, wl = sort_by_loc(wf, wl)
+        assert np.array_equal(gl, wl.astype(np.int64))
+        assert rel_err(gf, wf) < 2e-4, gf.shape
+
+
+def test_3g6c_grouped_tail_vs_oracle_at_full_size(full3g, dev):
+    """Per class group: proposals (top-k -> decode -> NMS survivor list) exact against the port's selector on the device's
+    scores; pooler / box head within tolerance; final boxes and original-class labels of the three groups bit-exact."""
+    cfg, model, orc, result, mid, rpn_w, roi_w, _ = full3g
+    G = 3
+    pre, post = cfg.MODEL.RPN.FPN_PRE_NMS_TOP_N_TEST, cfg.MODEL.RPN.FPN_POST_NMS_TOP_N_TEST
+    assert (pre, post, cfg.MODEL.ROI_HEADS.DETECTIONS_PER_IMG) == (1000, 500, 100)   # x 0.5 per group
+    with torch.no_grad():
+        obj, reg = model.rpn.head([f.features for f in mid["rpn_features"]])
+        assert obj.shape[1] == G and reg.shape[1] == 7 * G
+        maps = [(f.features.cpu().numpy(), f.get_spatial_locations().cpu().numpy()) for f in mid["rpn_features"]]
+        wo, wr, wanchors = orc.rpn_head(maps)
+        assert torch.allclose(obj.cpu(), wo, rtol=1e-3, atol=1e-4) and torch.allclose(reg.cpu(), wr, rtol=1e-3, atol=1e-4)
+        anchors = model.rpn.anchor_generator.forward_cat(mid["rpn_features"])
+        assert np.array_equal(anchors.cpu().numpy(), wanchors) and anchors.shape[0] > 40_000
+        props, sep_id = mid["proposals"], mid["sep_id"]
+        assert sep_id is not None and props.shape[0] == sep_id.shape[0]
+        scores = obj.sigmoid().cpu()
+        n_seen = 0
+        for g in range(G):
+            want_p, want_s, keep, _ = orc.rpn_select(None, reg[:, 7 * g:7 * g + 7].cpu(), wanchors, scores=scores[:, g])
+            want_p = want_p.copy()
+            want_p[:, 3:6] = np.maximum(want_p[:, 3:6], 0.001)                       # BoxList3D.clamp_size
+            got_p = props[sep_id == g].cpu().numpy()
+            assert 10 < len(keep) <= post
+            assert np.array_equal(got_p, want_p), g                                   # survivor list and decode, exact
+            n_seen += len(keep)
+        assert n_seen == props.shape[0]
+        # pooler on the device's maps and proposals, box head, grouped post-processing
+        fe = model.roi_heads.box.feature_extractor
+        p = props.clone()
+        p[:, 0:6] *= 50
+        pooled = fe.pooler(mid["roi_features"], p)
+        roi_g = [(f.features.cpu().numpy(), f.get_spatial_locations().cpu().numpy(), None) for f in mid["roi_features"]]
+        want_pooled = orc.pool(roi_g, props.cpu().numpy())
+        assert np.abs(pooled.cpu().numpy() - want_pooled).max() < 1e-5 * max(1, np.abs(want_pooled).max())
+        x = fe(mid["roi_features"], props)
+        logits, regb = model.roi_heads.box.predictor(x)
+        assert logits.shape[1] == 8 and regb.shape[1] == 56
+        wl, wrb = orc.box_head(want_pooled)
+        assert torch.allclose(logits.cpu(), wl, rtol=2e-3, atol=2e-4) and torch.allclose(regb.cpu(), wrb, rtol=2e-3, atol=2e-4)
+        wb, ws, wlab = orc.post_grouped(logits.cpu(), regb.cpu(), props.cpu().numpy(), sep_id.cpu().numpy())
+        got = model.roi_heads.box(mid["roi_features"], props, sep_id=sep_id)
+        assert got["bbox3d"].shape[0] == wb.shape[0] > 0
+        assert np.array_equal(got["labels"].cpu().numpy(), wlab) and set(wlab.tolist()).issubset({1, 2, 3, 4, 5})
+        assert np.array_equal(got["bbox3d"].cpu().numpy(), wb)
+        assert np.allclose(got["scores"].cpu().numpy(), ws, atol=1e-6)
+        for k in ("bbox3d", "scores", "labels"):
+            assert torch.equal(got[k], result[k])
+
+
+def test_3g6c_training_step_and_group_labels_at_full_size(full3g, dev):
+    """One 3G6c training step on the 500 k-point building: the three groups' target sets and RPN label sets
+    (rpn/loss_3d.py:88-109 per group, seperate_classifier.py:83-95) against the port's Matcher on the oracle IoU."""
+    from detection_3d_amd import box_ops
+    from detection_3d_amd import training as T
+    from oracle import detector_port as P
+    from tests.helpers import label_differences_sit_on_thresholds
+    cfg, model, orc, result, mid, rpn_w, roi_w, (coords, feats) = full3g
+    b, l, targets = _targets_3g(dev)
+    sep = model.rpn.sep
+    tg = sep.group_targets(targets)
+    want_tg = P.group_targets(orc.groups, b, l)
+    with torch.no_grad():
+        anchors = model.rpn.anchor_generator.forward_cat(mid["rpn_features"])
+    a_np = anchors.cpu().numpy()
+    lossf = model.rpn.loss_evaluator
+    rpn = cfg.MODEL.RPN
+    n_diff_total = 0
+    for g in range(3):
+        assert np.array_equal(tg[g]["bbox3d"].cpu().numpy(), want_tg[g][0])
+        assert np.array_equal(tg[g]["labels"].cpu().numpy(), want_tg[g][1])
+        gt = tg[g]["bbox3d"]
+        labels, _ = lossf.prepare_targets(anchors, gt)
+        labels = labels.cpu().numpy()
+        want, (q_o, yaw_o, _) = P.rpn_labels(cfg, a_np, want_tg[g][0], return_iou=True)
+        # (a) the device's Matcher on the device's own IoU = the port's Matcher on the same matrix, exactly
+        q_g = box_ops.boxes_iou_3d(gt, anchors, lossf.aug, criterion=2, flag='rpn_label_generation')
+        yaw_g = torch.abs(box_ops.limit_period(gt[:, -1].view(-1, 1) - anchors[:, -1].view(1, -1), 0.5, np.pi))
+        m = P.matcher(q_g.cpu().numpy(), rpn.FG_IOU_THRESHOLD, rpn.BG_IOU_THRESHOLD, True, yaw_g.cpu().numpy(), rpn.YAW_THRESHOLD)
+        same = (m >= 0).astype(np.float32)
+        same[m == -2] = -1
+        assert np.array_equal(labels, same), g
+        # (b) against the oracle IoU: the matrices agree to 1e-4, and a label differs only where an IoU sits on a threshold
+        assert np.array_equal(yaw_g.cpu().numpy(), yaw_o)
+        assert np.abs(q_g.cpu().numpy() - q_o).max() <= 1e-4
+        mask_g = (yaw_g.cpu().numpy() < np.float32(rpn.YAW_THRESHOLD)).astype(np.float32)
+        n_diff, bad = label_differences_sit_on_thresholds(labels, want, q_g.cpu().numpy() * mask_g, q_o * mask_g,
+                                                          rpn.BG_IOU_THRESHOLD, rpn.FG_IOU_THRESHOLD)
+        assert not bad, (g, n_diff, bad[:5])
+        n_diff_total += n_diff
+        assert (labels == 1).sum() >= max(1, gt.shape[0] // 2), g
+    assert n_diff_total <= 1e-3 * 3 * a_np.shape[0]
+    # the step itself
+    model.train()
+    try:
+        opt = T.make_optimizer(cfg, model)
+        losses = model([coords, feats], targets)
+        assert len(losses) == 12 and all(torch.isfinite(v) for v in losses.values()), losses
+        opt.zero_grad()
+        sum(losses.values()).backward()
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+        assert model.rpn.head.cls_logits.weight.grad.abs().sum() > 0
+        assert model.roi_heads.box.predictor.cls_score.weight.grad.abs().sum() > 0
+    finally:
+        model.eval()
