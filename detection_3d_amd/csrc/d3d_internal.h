@@ -143,11 +143,16 @@ struct d3d_meta {
   int32_t *in_off = nullptr, *in_idx = nullptr;
   int32_t *in_pslot = nullptr;   // hash slot of every input point (input for the point lists, built on first use)
   bool in_lists = false;         // in_off / in_idx filled (ensure_point_lists)
+  char *pl_scratch = nullptr;    // temporaries of the point lists, set aside by the input-layer build: the lists can then
+  size_t pl_scratch_bytes = 0;   // be sorted on ANY stream (no lane of the arena is touched)
   d3d::Size3 in_size = {0, 0, 0};  // spatial size of the input grid
+  int in_ext[4] = {0, 0, 0, 0};    // 1 + largest x, y, z, example index of the input points (read back with the site count)
   int32_t *iota = nullptr;         // 0 .. in_n - 1 (values of the plan sorts), written once per scene
   int iota_n = 0;
   // pinned host words for size read-backs
   long *host_words = nullptr;
+  int32_t *host_counts = nullptr;  // pinned int32[32]: the site counts of a grid chain, stored by k_store_counts
+  hipEvent_t chain_ev = nullptr;   // recorded behind that store
   // neighbour table of the input grid started by d3d_input_layer_build_prefetch while the site count was read back
   // (top of the geometry lane, which is shortened by it until d3d_meta_clear); consumed by d3d_subm_prepare
   int32_t *pre_nbr = nullptr;

@@ -342,15 +342,39 @@ static hipError_t fill_ones(void *ptr, size_t bytes, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------
 // a2. Input layer: hash insert + first-occurrence numbering (IOLayersRules.h:72-95).
-__global__ void k_insert_points(const int64_t *__restrict__ coords, int n, int ncols,
-                                HashEntry *tab, int cap, int32_t *pslot) {
+// ext (may be null): device int32[4] = 1 + the largest x, y, z and example index over all points (zero-initialised by the
+// caller): one atomicMax per dimension and 256-thread block.  The host reads it back with the site count and bounds the
+// site counts of the coarser grids with it (grid chain below), so that no further count has to be read back.
+__global__ __launch_bounds__(256) void k_insert_points(const int64_t *__restrict__ coords, int n, int ncols,
+                                                       HashEntry *tab, int cap, int32_t *pslot, int32_t *ext) {
+  __shared__ int red[4][4];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int64_t *c = coords + (size_t)i * ncols;
-  int b = ncols == 4 ? (int)c[3] : 0;
-  int slot = hash_insert(tab, cap, pack_key(b, (int)c[0], (int)c[1], (int)c[2]));
-  atomicMin(&tab[slot].first, (uint32_t)i);
-  pslot[i] = slot;
+  int v[4] = {0, 0, 0, 0};
+  if (i < n) {
+    const int64_t *c = coords + (size_t)i * ncols;
+    int b = ncols == 4 ? (int)c[3] : 0;
+    int slot = hash_insert(tab, cap, pack_key(b, (int)c[0], (int)c[1], (int)c[2]));
+    atomicMin(&tab[slot].first, (uint32_t)i);
+    pslot[i] = slot;
+    v[0] = (int)c[0] + 1;
+    v[1] = (int)c[1] + 1;
+    v[2] = (int)c[2] + 1;
+    v[3] = b + 1;
+  }
+  if (!ext) return;
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    int m = v[d];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][d] = m;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int d = threadIdx.x;
+    const int m = max(max(red[0][d], red[1][d]), max(red[2][d], red[3][d]));
+    if (m > 0) atomicMax(&ext[d], m);
+  }
 }
 __global__ void k_flag_first(const int32_t *__restrict__ pslot, const HashEntry *__restrict__ tab,
                              int n, int32_t *flag) {
@@ -421,9 +445,11 @@ __device__ __forceinline__ bool conv_entry(const ConvGeom &g, const int32_t *p, 
          (p[2] - o[2] * g.stride[2]);
   return true;
 }
+// n_in_dev (may be null): the input site count on the device, for a launch sized by an upper bound of it
 __global__ void k_conv_insert(const int32_t *__restrict__ loc, long n_entries, ConvGeom g,
-                              HashEntry *tab, int cap, int32_t *eslot) {
+                              HashEntry *tab, int cap, int32_t *eslot, const int32_t *__restrict__ n_in_dev) {
   long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_in_dev) n_entries = (long)*n_in_dev * g.max_out;
   if (e >= n_entries) return;
   int i = (int)(e / g.max_out), j = (int)(e % g.max_out);
   const int32_t *p = loc + (size_t)i * 4;
@@ -452,10 +478,12 @@ __global__ void k_conv_assign(const int32_t *__restrict__ loc, long n_entries, C
   loc_out[id * 4 + 2] = o[2];
   loc_out[id * 4 + 3] = p[3];
 }
+// nbr_dec may be null (no deconvolution / backward view of this rulebook will be asked for)
 __global__ void k_conv_fill(const int32_t *__restrict__ loc, long n_entries, ConvGeom g, int K,
                             const int32_t *__restrict__ eslot, const HashEntry *__restrict__ tab,
-                            int32_t *nbr_fwd, int32_t *nbr_dec) {
+                            int32_t *nbr_fwd, int32_t *nbr_dec, const int32_t *__restrict__ n_in_dev) {
   long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_in_dev) n_entries = (long)*n_in_dev * g.max_out;
   if (e >= n_entries || eslot[e] < 0) return;
   int i = (int)(e / g.max_out), j = (int)(e % g.max_out);
   const int32_t *p = loc + (size_t)i * 4;
@@ -463,7 +491,120 @@ __global__ void k_conv_fill(const int32_t *__restrict__ loc, long n_entries, Con
   conv_entry(g, p, j, o, &off);
   int oid = tab[eslot[e]].val;
   nbr_fwd[(size_t)oid * K + off] = i;
-  nbr_dec[(size_t)i * K + off] = oid;
+  if (nbr_dec) nbr_dec[(size_t)i * K + off] = oid;
+}
+
+// First-touch numbering of a strided grid's output sites without a scan over the entries: a tile of kChainTile entries
+// leaves its first-touch flags as 32 ballot words and their number (k_chain_flag); k_chain_assign then sums the counts of
+// the tiles before its own (a few hundred integers, no cross-workgroup waiting), ranks its flags with popcounts and writes
+// site ids, coordinates and -- the last tile -- the site count, all on the device.  Two launches for what k_flag_first,
+// the three scan kernels and k_conv_assign did in five, and nothing the host has to read before the next level starts.
+static constexpr int kChainTile = 2048;   // = 256 threads x 8 rounds; word w of a tile = its entries 64 w .. 64 w + 63
+__global__ __launch_bounds__(256) void k_chain_flag(const int32_t *__restrict__ eslot, const HashEntry *__restrict__ tab,
+                                                    long n_entries, int max_out, const int32_t *__restrict__ n_in_dev,
+                                                    unsigned long long *__restrict__ flagbits,
+                                                    int32_t *__restrict__ tile_cnt) {
+  __shared__ int wcnt[4];
+  if (n_in_dev) n_entries = (long)*n_in_dev * max_out;
+  const long base = (long)blockIdx.x * kChainTile;
+  if (base >= n_entries) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int w = j * 4 + wave;
+    const long e = base + w * 64 + lane;
+    bool f = false;
+    if (e < n_entries) {
+      const int sl = eslot[e];
+      f = sl >= 0 && tab[sl].first == (uint32_t)e;
+    }
+    const unsigned long long bal = __ballot(f);
+    if (lane == 0) flagbits[(size_t)blockIdx.x * 32 + w] = bal;
+    c += __popcll(bal);
+  }
+  if (lane == 0) wcnt[wave] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_cnt[blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+}
+__global__ __launch_bounds__(256) void k_chain_assign(const int32_t *__restrict__ loc, long n_entries, ConvGeom g,
+                                                      const int32_t *__restrict__ n_in_dev,
+                                                      const int32_t *__restrict__ eslot,
+                                                      const unsigned long long *__restrict__ flagbits,
+                                                      const int32_t *__restrict__ tile_cnt, HashEntry *tab,
+                                                      int32_t *__restrict__ loc_out, int32_t *__restrict__ n_out_dev) {
+  __shared__ int red[4];
+  __shared__ int wpre[33];
+  __shared__ unsigned long long words[32];
+  if (n_in_dev) n_entries = (long)*n_in_dev * g.max_out;
+  if (n_entries <= 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_out_dev = 0;
+    return;
+  }
+  const int n_tiles = (int)((n_entries + kChainTile - 1) / kChainTile);
+  if ((int)blockIdx.x >= n_tiles) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int part = 0;
+  for (int t = threadIdx.x; t < (int)blockIdx.x; t += 256) part += tile_cnt[t];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o, 64);
+  if (lane == 0) red[wave] = part;
+  if (threadIdx.x < 32) {
+    const unsigned long long w = flagbits[(size_t)blockIdx.x * 32 + threadIdx.x];
+    words[threadIdx.x] = w;
+    const int pc = __popcll(w);
+    int inc = pc;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+      const int t = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += t;
+    }
+    wpre[threadIdx.x] = inc - pc;
+    if (threadIdx.x == 31) wpre[32] = inc;
+  }
+  __syncthreads();
+  const int off = red[0] + red[1] + red[2] + red[3];
+  const long base = (long)blockIdx.x * kChainTile;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int w = j * 4 + wave;
+    const unsigned long long word = words[w];
+    if (!((word >> lane) & 1ull)) continue;
+    const long e = base + w * 64 + lane;
+    const int id = off + wpre[w] + __popcll(word & ((1ull << lane) - 1ull));
+    const int i = (int)(e / g.max_out), jj = (int)(e % g.max_out);
+    const int32_t *p = loc + (size_t)i * 4;
+    int o[3], offk;
+    conv_entry(g, p, jj, o, &offk);
+    tab[eslot[e]].val = id;
+    loc_out[(size_t)id * 4 + 0] = o[0];
+    loc_out[(size_t)id * 4 + 1] = o[1];
+    loc_out[(size_t)id * 4 + 2] = o[2];
+    loc_out[(size_t)id * 4 + 3] = p[3];
+  }
+  if ((int)blockIdx.x == n_tiles - 1 && threadIdx.x == 0) *n_out_dev = off + wpre[32];
+}
+// 0xFF fill of up to kFillSegs memory ranges in one launch (blockIdx.y = range)
+static constexpr int kFillSegs = 48;
+struct FillSegs {
+  uint4 *ptr[kFillSegs];
+  unsigned long long n16[kFillSegs];
+};
+__global__ __launch_bounds__(256) void k_fill_ones_multi(FillSegs f) {
+  const uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
+  uint4 *__restrict__ p = f.ptr[blockIdx.y];
+  const size_t n = f.n16[blockIdx.y];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+// the site counts of the chain's levels -> a pinned host array (one system-scope release store each)
+static constexpr int kChainMax = 24;
+struct CountPtrs {
+  const int32_t *p[kChainMax];
+  int n;
+};
+__global__ void k_store_counts(CountPtrs c, int32_t *__restrict__ host) {
+  const int i = threadIdx.x;
+  if (i < c.n) __hip_atomic_store(&host[i], *c.p[i], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // The whole strided-grid build of a SMALL level in one single-workgroup launch: table + rulebook initialisation,
@@ -475,20 +616,30 @@ __global__ void k_conv_fill(const int32_t *__restrict__ loc, long n_entries, Con
 // loads (L2), never through a possibly stale L1 line.
 static constexpr int kSmallGrid = 4096;                        // entries one workgroup takes (16 k: slower than the 11 launches)
 static constexpr int kSmallGridEPT = kSmallGrid / 1024;
+// n_in_dev (may be null): the input site count on the device (n_entries / n_in are then upper bounds; the grid chain);
+// prefilled: table and rulebook arrays already hold 0xFF (the chain's one fill launch); nbr_dec may be null.
 __global__ __launch_bounds__(1024) void k_conv_grid_small(const int32_t *__restrict__ loc, int n_entries, ConvGeom g,
                                                           int K, int n_in, HashEntry *tab, int cap,
                                                           int32_t *__restrict__ loc_out, int32_t *__restrict__ nbr_fwd,
-                                                          int32_t *__restrict__ nbr_dec, int32_t *__restrict__ total) {
+                                                          int32_t *__restrict__ nbr_dec, int32_t *__restrict__ total,
+                                                          const int32_t *__restrict__ n_in_dev, int prefilled) {
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   __shared__ int wsum[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const u32x4 ones = {~0u, ~0u, ~0u, ~0u};
-  for (int i = tid; i < cap; i += 1024) *(u32x4 *)&tab[i] = ones;
-  for (int i = tid; i < n_in * K + 1; i += 1024) nbr_dec[i] = -1;
-  for (int i = tid; i < n_entries * K + 1; i += 1024) nbr_fwd[i] = -1;      // n_out <= n_entries rows are read later
-  __syncthreads();   // every wave's stores have reached L2 ...
-  if (tid == 0) __threadfence();   // ... one agent-scope fence for the workgroup (as in k_bn_stats)
-  __syncthreads();
+  if (n_in_dev) {
+    n_in = *n_in_dev;
+    n_entries = n_in * g.max_out;
+  }
+  if (!prefilled) {
+    const u32x4 ones = {~0u, ~0u, ~0u, ~0u};
+    for (int i = tid; i < cap; i += 1024) *(u32x4 *)&tab[i] = ones;
+    if (nbr_dec)
+      for (int i = tid; i < n_in * K + 1; i += 1024) nbr_dec[i] = -1;
+    for (int i = tid; i < n_entries * K + 1; i += 1024) nbr_fwd[i] = -1;      // n_out <= n_entries rows are read later
+    __syncthreads();   // every wave's stores have reached L2 ...
+    if (tid == 0) __threadfence();   // ... one agent-scope fence for the workgroup (as in k_bn_stats)
+    __syncthreads();
+  }
   int slot_r[kSmallGridEPT];
 #pragma unroll
   for (int it = 0; it < kSmallGridEPT; it++) {
@@ -552,7 +703,7 @@ __global__ __launch_bounds__(1024) void k_conv_grid_small(const int32_t *__restr
     conv_entry(g, p, e % g.max_out, o, &off);
     const int oid = __hip_atomic_load(&tab[slot].val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     nbr_fwd[(size_t)oid * K + off] = i;
-    nbr_dec[(size_t)i * K + off] = oid;
+    if (nbr_dec) nbr_dec[(size_t)i * K + off] = oid;
   }
 }
 
@@ -1242,6 +1393,7 @@ int d3d_meta_create(d3d_meta **out, size_t arena_bytes) {
   m->feat_arena.base = m->arena.base + m->arena.cap;
   m->feat_arena.cap = m->feat_cap_full = feat_bytes;
   e = hipHostMalloc((void **)&m->host_words, 16 * sizeof(long), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void **)&m->host_counts, 32 * sizeof(int32_t), hipHostMallocDefault);
   if (e != hipSuccess) {
     set_error("hipHostMalloc failed: %s", hipGetErrorString(e));
     (void)hipFree(m->arena.base);
@@ -1256,7 +1408,9 @@ int d3d_meta_destroy(d3d_meta *m) {
   geo_async_free(m);
   (void)hipFree(m->arena.base);
   (void)hipHostFree(m->host_words);
+  if (m->host_counts) (void)hipHostFree(m->host_counts);
   if (m->count_ev) (void)hipEventDestroy(m->count_ev);
+  if (m->chain_ev) (void)hipEventDestroy(m->chain_ev);
   delete m;
   return D3D_OK;
 }
@@ -1278,7 +1432,10 @@ int d3d_meta_clear(d3d_meta *m) {
   m->plans.clear();
   m->strided_raw.clear();
   m->in_n = m->in_mode = m->in_active = 0;
+  for (int d = 0; d < 4; d++) m->in_ext[d] = 0;
   m->in_off = m->in_idx = m->in_pslot = nullptr;
+  m->pl_scratch = nullptr;
+  m->pl_scratch_bytes = 0;
   m->iota = nullptr;
   m->iota_n = 0;
   m->in_lists = false;
@@ -1381,6 +1538,11 @@ int d3d_voxelize(const float *pcl, int n, int nfeat, double scale, const int *fu
   return D3D_OK;
 }
 
+static size_t point_list_scratch_bytes(int n) {   // what ensure_point_lists carves: site of every point, counts, scan sums, sort
+  const size_t nn = (size_t)std::max(n, 1);
+  return nn * 4 + 256 + (nn + 2) * 4 + 256 + ((nn + 1 + kScanTile - 1) / kScanTile) * 4 + 256 + sort_scratch_bytes(n, 32) + 4096;
+}
+
 int d3d_input_layer_build(d3d_meta *m, const int64_t *coords, int n, int ncols, const int *size,
                           int batch_size, int mode, void *stream, int *n_active_host) {
   return d3d_input_layer_build_prefetch(m, coords, n, ncols, size, batch_size, mode, nullptr, stream, n_active_host);
@@ -1413,6 +1575,12 @@ int d3d_input_layer_build_prefetch(d3d_meta *m, const int64_t *coords, int n, in
   D3D_ALLOC(in_idx, int32_t, A, (size_t)n + 1);
   D3D_ALLOC(pslot, int32_t, A, (size_t)n + 1);
   D3D_ALLOC(iota, int32_t, A, (size_t)n + 1);   // 0, 1, 2, ...: the values every plan sort permutes (no grid has more rows)
+  {
+    const size_t pl = point_list_scratch_bytes(n);
+    D3D_ALLOC(pls, char, A, pl);
+    m->pl_scratch = pls;
+    m->pl_scratch_bytes = pl;
+  }
   m->iota = iota;
   m->iota_n = n;
   if (n > 0) hipLaunchKernelGGL(k_iota, grid1d(n), dim3(256), 0, s, iota, n);
@@ -1431,14 +1599,15 @@ int d3d_input_layer_build_prefetch(d3d_meta *m, const int64_t *coords, int n, in
     size_t mark = A.used;
     D3D_ALLOC(flag, int32_t, A, n);
     D3D_ALLOC(rank, int32_t, A, n);
-    D3D_ALLOC(total, int32_t, A, 1);
-    hipLaunchKernelGGL(k_insert_points, grid1d(n), dim3(256), 0, s, coords, n, ncols, tab, g.cap, pslot);
+    D3D_ALLOC(total, int32_t, A, 8);            // [0] site count, [1..4] extents of the points (k_insert_points)
+    D3D_HIP_CHECK(hipMemsetAsync(total, 0, 8 * sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_insert_points, grid1d(n), dim3(256), 0, s, coords, n, ncols, tab, g.cap, pslot, total + 1);
     hipLaunchKernelGGL(k_flag_first, grid1d(n), dim3(256), 0, s, pslot, tab, n, flag);
     int rc = scan_exclusive_i32(flag, rank, n, total, A, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_assign_input_sites, grid1d(n), dim3(256), 0, s, coords, n, ncols, pslot, flag, rank, tab, loc);
     D3D_LAUNCH_CHECK();
-    D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[0], total, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[0], total, 5 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     bool prefetched = false;
     if (prefetch_filter) {
       // The neighbour table of the submanifold rulebook the caller will ask for first (hash probes of every site,
@@ -1463,6 +1632,7 @@ int d3d_input_layer_build_prefetch(d3d_meta *m, const int64_t *coords, int n, in
     if (prefetched) D3D_HIP_CHECK(hipEventSynchronize(m->count_ev));
     else D3D_HIP_CHECK(hipStreamSynchronize(s));
     n_active = (int)*(int32_t *)&m->host_words[0];
+    for (int d = 0; d < 4; d++) m->in_ext[d] = ((const int32_t *)&m->host_words[0])[1 + d];
     A.used = mark;
   }
   g.n = n_active;
@@ -1490,7 +1660,10 @@ int ensure_point_lists(d3d_meta *m, hipStream_t s) {
     it = m->grids.find(m->in_size);
     D3D_REQUIRE(it != m->grids.end(), "input layer: grid not found");
   }
-  Arena &A = lane_arena(m, s);
+  Arena own;                      // the region the build set aside: independent of the stream's lane
+  own.base = m->pl_scratch;
+  own.cap = m->pl_scratch_bytes;
+  Arena &A = m->pl_scratch ? own : lane_arena(m, s);
   size_t mark = A.used;
   D3D_ALLOC(psite, uint32_t, A, n);
   D3D_ALLOC(cnt, int32_t, A, (size_t)n + 1);
@@ -1781,7 +1954,7 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
       size_t mark = A.used;
       D3D_ALLOC(total, int32_t, A, 1);
       hipLaunchKernelGGL(k_conv_grid_small, dim3(1), dim3(1024), 0, s, gi->loc, (int)n_entries, geo, K, n_in, tab, go.cap,
-                         loc_out, nbr_fwd, nbr_dec, total);
+                         loc_out, nbr_fwd, nbr_dec, total, (const int32_t *)nullptr, 0);
       D3D_LAUNCH_CHECK();
       D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[1], total, sizeof(int32_t), hipMemcpyDeviceToHost, s));
       D3D_HIP_CHECK(hipStreamSynchronize(s));
@@ -1805,7 +1978,8 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
       D3D_ALLOC(flag, int32_t, A, n_entries);
       D3D_ALLOC(rank, int32_t, A, n_entries);
       D3D_ALLOC(total, int32_t, A, 1);
-      hipLaunchKernelGGL(k_conv_insert, grid1d(n_entries), dim3(256), 0, s, gi->loc, n_entries, geo, tab, go.cap, eslot);
+      hipLaunchKernelGGL(k_conv_insert, grid1d(n_entries), dim3(256), 0, s, gi->loc, n_entries, geo, tab, go.cap, eslot,
+                         (const int32_t *)nullptr);
       hipLaunchKernelGGL(k_flag_first, grid1d(n_entries), dim3(256), 0, s, eslot, tab, (int)n_entries, flag);
       int rc = scan_exclusive_i32(flag, rank, (int)n_entries, total, A, s);
       if (rc) return rc;
@@ -1815,7 +1989,8 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
       n_out = (int)*(int32_t *)&m->host_words[1];
       publish_grid(m, go, n_out, out_size, s);
       D3D_HIP_CHECK(fill_ones(nbr_fwd, sizeof(int32_t) * ((size_t)n_out * K + 1), s));
-      hipLaunchKernelGGL(k_conv_fill, grid1d(n_entries), dim3(256), 0, s, gi->loc, n_entries, geo, K, eslot, tab, nbr_fwd, nbr_dec);
+      hipLaunchKernelGGL(k_conv_fill, grid1d(n_entries), dim3(256), 0, s, gi->loc, n_entries, geo, K, eslot, tab, nbr_fwd, nbr_dec,
+                         (const int32_t *)nullptr);
       D3D_LAUNCH_CHECK();
       A.used = mark;
       rc = finalize_plan(m, nbr_fwd, n_out, K, p, s, nullptr);
@@ -1842,11 +2017,283 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
 }  // extern "C" (reopened below)
 
 namespace d3d {
-static void geo_run_grids(d3d_meta *m, GeoAsync *g) {      // the grids, in order; each one blocks on its count read-back
+// ------------------------------------------------------------------------------------------------------------------
+// Grid chain: the strided grids (+ raw rule tables) of a whole pyramid enqueued WITHOUT a host read-back between the
+// levels.  d3d_conv_prepare reads every new grid's site count back before it can size the next level's launches and
+// allocations: 11 stream synchronisations per building, each with the GPU idle on that stream for the round trip.  Here
+// every level is sized by an upper bound known ahead of time -- sites(out) <= min(entries(in), cells of the occupied box
+// at that level), from the input grid's site count and coordinate extents, which arrive in ONE read-back -- its kernels
+// read the true count from the device word the level before left, all tables get their 0xFF fill in one launch up
+// front, and the counts of all levels come back together behind the last kernel (k_store_counts -> pinned words, one
+// event).  Only then are the grids published and the rulebooks finalised (exact sizes), in order.
+// Results are those of d3d_conv_prepare bit for bit: same insertion, same first-touch numbering, same tables.
+struct ChainSpec {              // one strided rulebook: sizes as d3d_conv_prepare takes them
+  int in_size[3], out_size[3], filt[3], stride[3];
+  int need_dec;                 // keep the decoded table (deconvolution / backward view will be asked for)
+};
+typedef void (*ChainHook)(void *arg, int level, int n_out, hipStream_t s);   // level published / level's rulebook enqueued
+
+static int run_grid_chain(d3d_meta *m, const std::vector<ChainSpec> &specs, hipStream_t s, std::vector<int> &n_out,
+                          ChainHook on_grid, ChainHook on_done, void *hook_arg) {
+  const int L = (int)specs.size();
+  n_out.assign(L, 0);
+  if (L == 0) return D3D_OK;
+  D3D_REQUIRE(L <= kChainMax, "grid chain: %d levels (at most %d)", L, kChainMax);
+  if (int rc = check_build_stream(m, s, "grid chain")) return rc;
+  struct Level {
+    ConvGeom geo;
+    int K = 0;
+    const int32_t *loc_in = nullptr;
+    const int32_t *n_in_dev = nullptr;   // null: n_in_host is exact
+    int n_in_host = 0, src = -1;         // src: chain level that produces the input grid, or -1
+    long bound_in = 0, bound_entries = 0, bound_out = 0;
+    int ext_out[4] = {0, 0, 0, 0};
+    Grid go;
+    int32_t *n_out_dev = nullptr, *eslot = nullptr, *tile_cnt = nullptr, *nbr_fwd = nullptr, *nbr_dec = nullptr;
+    unsigned long long *flagbits = nullptr;
+    bool small = false;
+  };
+  std::vector<Level> lv(L);
+  std::map<Size3, int> made;             // output size -> chain level
+  Arena &A = m->arena;
+  const size_t cap_save = A.cap;
+  struct Restore {                        // the raw tables sit at the far end of the lane until the rulebooks are enqueued
+    Arena &a;
+    size_t cap;
+    ~Restore() { a.cap = cap; }
+  } restore{A, cap_save};
+  auto top = [&](size_t bytes) -> void * {
+    bytes = (bytes + 255) & ~size_t(255);
+    if (A.used + bytes + (size_t)(1 << 20) > A.cap) return nullptr;
+    A.cap = (A.cap - bytes) & ~size_t(255);
+    return A.base + A.cap;
+  };
+  FillSegs fs = {};
+  int n_seg = 0;
+  D3D_REQUIRE(3 * L <= kFillSegs, "grid chain: too many levels for one fill launch");
+  auto add_fill = [&](void *p, size_t bytes) {   // bytes rounded up to 16 (allocations are 256-byte aligned and padded)
+    fs.ptr[n_seg] = (uint4 *)p;
+    fs.n16[n_seg] = (bytes + 15) / 16;
+    n_seg++;
+  };
+  for (int i = 0; i < L; i++) {
+    const ChainSpec &sp = specs[i];
+    Level &v = lv[i];
+    int K = 1, max_out = 1;
+    for (int d = 0; d < 3; d++) {
+      D3D_REQUIRE(sp.filt[d] > 0 && sp.stride[d] > 0 && sp.out_size[d] > 0, "bad filter/stride/size");
+      D3D_REQUIRE((sp.out_size[d] - 1) * sp.stride[d] + sp.filt[d] == sp.in_size[d],
+                  "convolution sizes inconsistent: (out-1)*stride+filter != in (convolution.py:37-38)");
+      v.geo.filt[d] = sp.filt[d];
+      v.geo.stride[d] = sp.stride[d];
+      v.geo.out_size[d] = sp.out_size[d];
+      K *= sp.filt[d];
+      max_out *= std::min((sp.filt[d] + sp.stride[d] - 1) / sp.stride[d], sp.out_size[d]);
+    }
+    v.geo.max_out = max_out;
+    v.K = K;
+    D3D_REQUIRE(K <= 32, "filter volume %d not supported (<= 32)", K);
+    D3D_REQUIRE(max_out <= 8, "each input site may feed at most 8 outputs");
+    const Size3 in_sz{sp.in_size[0], sp.in_size[1], sp.in_size[2]}, out_sz{sp.out_size[0], sp.out_size[1], sp.out_size[2]};
+    if (find_grid(m, sp.out_size) || made.count(out_sz)) {
+      set_error("grid chain: output grid [%d,%d,%d] already exists", sp.out_size[0], sp.out_size[1], sp.out_size[2]);
+      return D3D_ERR_STATE;
+    }
+    int ext_in[4];
+    auto src = made.find(in_sz);
+    if (src != made.end()) {
+      const Level &u = lv[src->second];
+      v.src = src->second;
+      v.loc_in = u.go.loc;
+      v.n_in_dev = u.n_out_dev;
+      v.bound_in = u.bound_out;
+      for (int d = 0; d < 4; d++) ext_in[d] = u.ext_out[d];
+    } else {
+      Grid *gi = find_grid(m, sp.in_size);
+      if (!gi) {
+        set_error("grid chain: no grid of spatial size [%d,%d,%d]", sp.in_size[0], sp.in_size[1], sp.in_size[2]);
+        return D3D_ERR_STATE;
+      }
+      v.loc_in = gi->loc;
+      v.n_in_host = gi->n;
+      v.bound_in = gi->n;
+      const bool is_input = in_sz == m->in_size && m->in_ext[0] > 0;
+      for (int d = 0; d < 3; d++) ext_in[d] = is_input ? m->in_ext[d] : sp.in_size[d];
+      ext_in[3] = is_input ? m->in_ext[3] : 0;        // 0: number of examples unknown -> no cell bound
+    }
+    v.bound_entries = v.bound_in * max_out;
+    long cells = ext_in[3] > 0 ? ext_in[3] : -1;
+    for (int d = 0; d < 3; d++) {
+      v.ext_out[d] = std::max(1, std::min(sp.out_size[d], (ext_in[d] - 1) / sp.stride[d] + 1));
+      if (cells >= 0) cells = std::min<long>(cells * v.ext_out[d], (long)1 << 40);
+    }
+    v.ext_out[3] = ext_in[3];
+    v.bound_out = cells >= 0 ? std::min(v.bound_entries, cells) : v.bound_entries;
+    D3D_REQUIRE(v.bound_entries < (1L << 30), "grid chain: %ld candidate entries", v.bound_entries);
+    v.small = v.bound_entries > 0 && v.bound_entries <= kSmallGrid;
+    // persistent: table, coordinates, decoded rule table; temporaries (far end): entry slots, flags, raw forward table
+    for (int d = 0; d < 3; d++) v.go.size[d] = sp.out_size[d];
+    v.go.cap = next_pow2(2L * std::max<long>(v.bound_out, 1));
+    D3D_ALLOC(tab, HashEntry, A, v.go.cap);
+    D3D_ALLOC(loc_out, int32_t, A, (size_t)v.bound_out * 4 + 4);
+    D3D_ALLOC(cnt, int32_t, A, 4);
+    v.go.tab = tab;
+    v.go.loc = loc_out;
+    v.n_out_dev = cnt;
+    if (v.bound_entries > 0) add_fill(tab, sizeof(HashEntry) * (size_t)v.go.cap);
+    if (sp.need_dec) {
+      D3D_ALLOC(dec, int32_t, A, (size_t)v.bound_in * K + 4);
+      v.nbr_dec = dec;
+      if (v.bound_entries > 0) add_fill(dec, sizeof(int32_t) * ((size_t)v.bound_in * K + 1));
+    }
+    if (v.bound_entries > 0) {
+      const size_t fwd_bytes = sizeof(int32_t) * ((size_t)v.bound_out * K + 4);
+      v.nbr_fwd = (int32_t *)top(fwd_bytes);
+      if (!v.small) {
+        const size_t tiles = ((size_t)v.bound_entries + kChainTile - 1) / kChainTile;
+        v.eslot = (int32_t *)top(sizeof(int32_t) * (size_t)v.bound_entries);
+        v.flagbits = (unsigned long long *)top(sizeof(unsigned long long) * tiles * 32);
+        v.tile_cnt = (int32_t *)top(sizeof(int32_t) * tiles);
+      }
+      if (!v.nbr_fwd || (!v.small && (!v.eslot || !v.flagbits || !v.tile_cnt))) {
+        set_error("metadata arena exhausted while building a grid chain");
+        return D3D_ERR_NOMEM;
+      }
+      add_fill(v.nbr_fwd, fwd_bytes);
+    }
+    made[out_sz] = i;
+  }
+  // one fill for every table of every level, then the levels back to back
+  if (n_seg > 0) {
+    size_t most = 0;
+    for (int j = 0; j < n_seg; j++) most = std::max<size_t>(most, fs.n16[j]);
+    const unsigned bx = (unsigned)std::max<size_t>(1, std::min<size_t>((most + 1023) / 1024, 512));
+    hipLaunchKernelGGL(k_fill_ones_multi, dim3(bx, n_seg), dim3(256), 0, s, fs);
+  }
+  CountPtrs cp = {};
+  cp.n = L;
+  for (int i = 0; i < L; i++) {
+    Level &v = lv[i];
+    cp.p[i] = v.n_out_dev;
+    if (v.bound_entries == 0) {
+      D3D_HIP_CHECK(hipMemsetAsync(v.n_out_dev, 0, sizeof(int32_t), s));
+      continue;
+    }
+    if (v.small) {
+      hipLaunchKernelGGL(k_conv_grid_small, dim3(1), dim3(1024), 0, s, v.loc_in, (int)v.bound_entries, v.geo, v.K,
+                         (int)v.bound_in, v.go.tab, v.go.cap, v.go.loc, v.nbr_fwd, v.nbr_dec, v.n_out_dev, v.n_in_dev, 1);
+      continue;
+    }
+    const long ne = v.bound_entries;
+    const dim3 tiles((unsigned)((ne + kChainTile - 1) / kChainTile));
+    hipLaunchKernelGGL(k_conv_insert, grid1d(ne), dim3(256), 0, s, v.loc_in, ne, v.geo, v.go.tab, v.go.cap, v.eslot, v.n_in_dev);
+    hipLaunchKernelGGL(k_chain_flag, tiles, dim3(256), 0, s, v.eslot, v.go.tab, ne, v.geo.max_out, v.n_in_dev, v.flagbits,
+                       v.tile_cnt);
+    hipLaunchKernelGGL(k_chain_assign, tiles, dim3(256), 0, s, v.loc_in, ne, v.geo, v.n_in_dev, v.eslot, v.flagbits,
+                       v.tile_cnt, v.go.tab, v.go.loc, v.n_out_dev);
+    hipLaunchKernelGGL(k_conv_fill, grid1d(ne), dim3(256), 0, s, v.loc_in, ne, v.geo, v.K, v.eslot, v.go.tab, v.nbr_fwd,
+                       v.nbr_dec, v.n_in_dev);
+  }
+  hipLaunchKernelGGL(k_store_counts, dim3(1), dim3(64), 0, s, cp, m->host_counts);
+  D3D_LAUNCH_CHECK();
+  if (!m->chain_ev) D3D_HIP_CHECK(hipEventCreateWithFlags(&m->chain_ev, hipEventDisableTiming));
+  D3D_HIP_CHECK(hipEventRecord(m->chain_ev, s));
+  D3D_HIP_CHECK(hipEventSynchronize(m->chain_ev));          // the one read-back of the chain
+  for (int i = 0; i < L; i++) {
+    n_out[i] = ((volatile int32_t *)m->host_counts)[i];
+    D3D_REQUIRE(n_out[i] >= 0 && n_out[i] <= lv[i].bound_out, "grid chain: level %d has %d sites, bound %ld", i, n_out[i],
+                lv[i].bound_out);
+  }
+  // the grids exist: publish them all, then the rulebooks (exact sizes) in order
+  for (int i = 0; i < L; i++) {
+    lv[i].go.n = n_out[i];
+    {
+      D3D_LOCK(m);
+      m->grids[Size3{specs[i].out_size[0], specs[i].out_size[1], specs[i].out_size[2]}] = lv[i].go;
+    }
+    if (on_grid) on_grid(hook_arg, i, n_out[i], s);
+  }
+  for (int i = 0; i < L; i++) {
+    Level &v = lv[i];
+    const ChainSpec &sp = specs[i];
+    const int n_in = v.src >= 0 ? n_out[v.src] : v.n_in_host;
+    Plan p;
+    int rc = finalize_plan(m, v.nbr_fwd, n_out[i], v.K, p, s, nullptr);
+    if (rc) return rc;
+    {
+      D3D_LOCK(m);
+      const PlanKey key = make_key(1, sp.in_size, sp.filt, sp.stride);
+      if (v.nbr_dec) {
+        StridedRaw raw;
+        raw.nbr_dec = v.nbr_dec;
+        raw.n_in = n_in;
+        raw.out_size = Size3{sp.out_size[0], sp.out_size[1], sp.out_size[2]};
+        m->strided_raw[key] = raw;
+      }
+      p.n_in = n_in;
+      m->plans.emplace(key, p);
+    }
+    if (on_done) on_done(hook_arg, i, n_out[i], s);
+  }
+  return D3D_OK;
+}
+
+// D3D_GRID_CHAIN=0: one d3d_conv_prepare (and read-back) per level, for A/B runs
+static const bool g_chain_enabled = [] {
+  const char *e = getenv("D3D_GRID_CHAIN");
+  return !(e && e[0] == '0');
+}();
+
+static void geo_run_grids(d3d_meta *m, GeoAsync *g) {      // the grids of the chain; ONE read-back for all of them
   int rc = geo_begin(g);
   const int n = (int)g->specs.size();
-  for (int i = 0; i < n; i++) {
-    if (g->specs[i][0] != 1) continue;
+  std::vector<int> rows;
+  for (int i = 0; i < n; i++)
+    if (g->specs[i][0] == 1 || g->specs[i][0] == 3) rows.push_back(i);
+  if (rows.empty()) return;
+  struct Hook {
+    GeoAsync *g;
+    const std::vector<int> *rows;
+    bool failed;
+  } hk = {g, &rows, false};
+  if (g_chain_enabled && rc == D3D_OK) {
+    std::vector<ChainSpec> specs(rows.size());
+    for (size_t j = 0; j < rows.size(); j++) {
+      const int *sp = g->specs[rows[j]].data() + 1;
+      for (int d = 0; d < 3; d++) {
+        specs[j].in_size[d] = sp[d];
+        specs[j].out_size[d] = sp[3 + d];
+        specs[j].filt[d] = sp[6 + d];
+        specs[j].stride[d] = sp[9 + d];
+      }
+      specs[j].need_dec = g->specs[rows[j]][0] == 1;      // kind 3: a strided grid whose decoded table nobody will ask for
+    }
+    std::vector<int> n_out;
+    rc = run_grid_chain(
+        m, specs, g->stream, n_out,
+        [](void *a, int level, int, hipStream_t on) {       // the grid exists: its submanifold views may start
+          Hook *h = (Hook *)a;
+          const int i = (*h->rows)[level];
+          if (hipEventRecord(h->g->gev[i], on) != hipSuccess) return;
+          std::lock_guard<std::mutex> lk(h->g->mu);
+          h->g->grid_ready[i] = 1;
+          h->g->cv.notify_all();
+        },
+        [](void *a, int level, int n_sites, hipStream_t on) {   // its strided rulebook is enqueued
+          Hook *h = (Hook *)a;
+          const int i = (*h->rows)[level];
+          int rc2 = D3D_OK;
+          if (hipEventRecord(h->g->ev[i], on) != hipSuccess) {
+            set_error("geometry thread: hipEventRecord failed");
+            rc2 = D3D_ERR_HIP;
+          }
+          if (!geo_publish(h->g, i, rc2, n_sites)) h->failed = true;
+        },
+        &hk);
+    if (rc != D3D_OK) geo_publish(g, rows[0], rc, 0);
+    return;
+  }
+  for (int i : rows) {
     const int *sp = g->specs[i].data() + 1;
     int n_out = 0;
     struct Mark {
@@ -1876,7 +2323,7 @@ static void geo_run_views(d3d_meta *m, GeoAsync *g) {      // the views: each be
   int dep = -1;
   for (int i = 0; i < n; i++) {
     const int kind = g->specs[i][0];
-    if (kind == 1) {
+    if (kind == 1 || kind == 3) {
       dep = i;
       continue;
     }
@@ -1914,9 +2361,9 @@ int d3d_geometry_async_start(d3d_meta *m, const int *specs, int n, void *stream,
               "geometry_async_start: `stream` must be the metadata's geometry stream (d3d_meta_set_geometry_stream)");
   for (int i = 0; i < n; i++) {
     const int kind = specs[i * 13];
-    D3D_REQUIRE(kind >= 0 && kind <= 2, "geometry_async_start: entry %d has kind %d (0 submanifold view, 1 strided grid, "
-                "2 deconvolution view)", i, kind);
-    D3D_REQUIRE(kind == 1 || (view_stream && (hipStream_t)view_stream == m->plan_stream),
+    D3D_REQUIRE(kind >= 0 && kind <= 3, "geometry_async_start: entry %d has kind %d (0 submanifold view, 1 strided grid, "
+                "2 deconvolution view, 3 strided grid without a deconvolution view)", i, kind);
+    D3D_REQUIRE(kind == 1 || kind == 3 || (view_stream && (hipStream_t)view_stream == m->plan_stream),
                 "geometry_async_start: views need the metadata's plan stream (d3d_meta_set_plan_stream)");
   }
   geo_async_join(m);

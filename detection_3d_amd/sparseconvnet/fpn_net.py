@@ -162,7 +162,10 @@ class FPN_Net(torch.nn.Module):
                 filt = scn.toLongTensor(self.dimension, self.down_kernels[k - 1])
                 stride = scn.toLongTensor(self.dimension, self.down_strides[k - 1])
                 out = (size - filt) // stride + 1
-                specs.append([1] + size.tolist() + out.tolist() + filt.tolist() + stride.tolist())
+                # kind 3: no deconvolution / backward view of this rulebook will be asked for (inference, below the
+                # finest level the top-down path reaches): its decoded table is not built
+                need_dec = self.training or torch.is_grad_enabled() or k > lowest_up or not views
+                specs.append([1 if need_dec else 3] + size.tolist() + out.tolist() + filt.tolist() + stride.tolist())
                 if views and k > lowest_up:
                     later.append([2] + out.tolist() + size.tolist() + filt.tolist() + stride.tolist())
                 size = out
@@ -170,7 +173,9 @@ class FPN_Net(torch.nn.Module):
             if k in pro2d:
                 conv = pro2d[k]
                 out = (size - conv.filter_size) // conv.filter_stride + 1
-                specs.append([1] + size.tolist() + out.tolist() + conv.filter_size.tolist() + conv.filter_stride.tolist())
+                need_dec = self.training or torch.is_grad_enabled()
+                specs.append([1 if need_dec else 3] + size.tolist() + out.tolist() + conv.filter_size.tolist()
+                             + conv.filter_stride.tolist())
             grid_row = len(specs) - 1 if (k > 0 or k in pro2d) else -1     # the level's last grid / strided rulebook
             view_row = -1
             if views:
@@ -200,25 +205,38 @@ class FPN_Net(torch.nn.Module):
         plan0 = pool[-1]
         state = {}
 
+        # both side streams start behind what the caller's stream held when the pass began (arena reuse from scene to scene
+        # is ordered by that stream); they do NOT wait for what the pass itself enqueues there, see below
+        scene_start = pool[-2]
+        scene_start.record(main)
+
         def after_input_build(md, size):
-            geo.wait_stream(main)
+            # The host has just seen the input grid's site count, i.e. the grid is complete: the side streams need not
+            # wait for the caller's stream, which already holds the hash probes of level 0's rulebook (~0.1 ms).
+            geo.wait_event(scene_start)
             md.set_geometry_stream(geo.cuda_stream)
-            # level 0's 3x3x3 rulebook on this stream (hash probes + sort, ~0.3 ms) while the geometry stream sorts the
-            # point lists; the plan lane is carved out of the feature lane only afterwards, and its stream starts behind
-            # this build (whose scratch may reach into what becomes the plan lane)
+            if plan is not None:
+                plan.wait_event(scene_start)
+                with torch.cuda.stream(plan):
+                    scn.SCN.InputLayer_prepare(md)          # point lists: own scratch (no lane of the arena), ~0.1 ms
+                    plan0.record(plan)
+            else:
+                with torch.cuda.stream(geo):
+                    scn.SCN.InputLayer_prepare(md)
+                    plan0.record(geo)
+            # level 0's 3x3x3 rulebook on this stream (sort + transpose of the probed table, ~0.15 ms); the plan lane is
+            # carved out of the feature lane only afterwards, and its stream continues behind this build (whose scratch
+            # may reach into what becomes the plan lane)
             scn.SCN.SubmanifoldConvolution_prepare(size, (3,) * self.dimension, md)
             if plan is not None:
                 plan.wait_stream(main)
                 md.set_plan_stream(plan.cuda_stream)
-            with torch.cuda.stream(geo):
-                scn.SCN.InputLayer_prepare(md)              # point lists (geometry lane of the arena) first ...
-                plan0.record(geo)
             cache = getattr(self, "_spec_cache", None)
-            key = tuple(scn.SCN._size3(size)) + (plan is not None,)
+            key = tuple(scn.SCN._size3(size)) + (plan is not None, bool(self.training), torch.is_grad_enabled())
             if cache is None or cache[0] != key:
                 cache = self._spec_cache = (key,) + self._geometry_specs(size, views=plan is not None)
             state["last"], state["all"] = cache[2], cache[3]
-            # ... then both lanes belong to the chain's thread
+            # the chain of strided grids starts at once on the geometry stream (one read-back for all of its levels)
             md.geometry_async_start(cache[1], geo.cuda_stream, plan.cuda_stream if plan is not None else None)
             state["md"] = md
             main.wait_event(plan0)

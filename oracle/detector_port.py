@@ -314,9 +314,11 @@ class OracleDetector:
         x = F.relu(_lin(sd, pre + "fc7", x))
         return _lin(sd, "roi_heads.box.predictor.cls_score", x), _lin(sd, "roi_heads.box.predictor.bbox_pred", x)
 
-    def post(self, logits, reg, proposals):
+    def post(self, logits, reg, proposals, prob=None):
+        """prob: the class probabilities to select on instead of this side's own softmax (the device's expf differs from
+        libm's in the last bit, which reorders near-tied candidates; tests hand in the device's values)."""
         rh = self.cfg.MODEL.ROI_HEADS
-        prob = F.softmax(logits, -1).numpy()
+        prob = F.softmax(logits, -1).numpy() if prob is None else np.asarray(prob, np.float32)
         nc = prob.shape[1]
         reg = reg.numpy()
         ob, os_, ol = [], [], []
@@ -336,10 +338,11 @@ class OracleDetector:
             b, s, l = b[k], s[k], l[k]
         return b, s, l
 
-    def post_grouped(self, logits, reg, proposals, sep_id):
+    def post_grouped(self, logits, reg, proposals, sep_id, probs=None):
         """SeperateClassifier.post_processor (seperate_classifier.py:299-321): rows of group g restricted to the group's
         class columns (:217-234), the plain post-processor per group (DETECTIONS_PER_IMG already scaled), labels mapped
-        back to the original class ids, groups concatenated in order.  -> (boxes, scores, labels)"""
+        back to the original class ids, groups concatenated in order.  probs: per group the probabilities of its rows (see
+        `post`).  -> (boxes, scores, labels)"""
         sep_id = np.asarray(sep_id)
         n = logits.shape[0]
         ob, os_, ol = [], [], []
@@ -348,7 +351,8 @@ class OracleDetector:
             c = torch.tensor(cols)
             lg = logits[ids][:, c]
             rg = reg.view(n, -1, 7)[:, c, :].reshape(n, -1)[ids]
-            b, sc, lab = self.post(lg, rg, np.asarray(proposals, np.float32)[ids.numpy()])
+            b, sc, lab = self.post(lg, rg, np.asarray(proposals, np.float32)[ids.numpy()],
+                                   None if probs is None else probs[g])
             ob.append(b); os_.append(sc); ol.append(np.asarray(cols, np.int64)[lab])
         return np.concatenate(ob), np.concatenate(os_), np.concatenate(ol)
 

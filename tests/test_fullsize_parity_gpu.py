@@ -331,6 +331,7 @@ def test_3g6c_backbone_maps_vs_oracle_at_full_size(full3g):
 def test_3g6c_grouped_tail_vs_oracle_at_full_size(full3g, dev):
     """Per class group: proposals (top-k -> decode -> NMS survivor list) exact against the port's selector on the device's
     scores; pooler / box head within tolerance; final boxes and original-class labels of the three groups bit-exact."""
+    import torch.nn.functional as F
     cfg, model, orc, result, mid, rpn_w, roi_w, _ = full3g
     G = 3
     pre, post = cfg.MODEL.RPN.FPN_PRE_NMS_TOP_N_TEST, cfg.MODEL.RPN.FPN_POST_NMS_TOP_N_TEST
@@ -369,12 +370,17 @@ def test_3g6c_grouped_tail_vs_oracle_at_full_size(full3g, dev):
         assert logits.shape[1] == 8 and regb.shape[1] == 56
         wl, wrb = orc.box_head(want_pooled)
         assert torch.allclose(logits.cpu(), wl, rtol=2e-3, atol=2e-4) and torch.allclose(regb.cpu(), wrb, rtol=2e-3, atol=2e-4)
-        wb, ws, wlab = orc.post_grouped(logits.cpu(), regb.cpu(), props.cpu().numpy(), sep_id.cpu().numpy())
+        # (selection on the device's own probabilities: softmax over each group's columns, rows of that group)
+        probs = [F.softmax(logits[sep_id == g][:, torch.tensor(cols, device=dev)], -1).cpu().numpy()
+                 for g, cols in enumerate(orc.groups)]
+        wb, ws, wlab = orc.post_grouped(logits.cpu(), regb.cpu(), props.cpu().numpy(), sep_id.cpu().numpy(), probs)
         got = model.roi_heads.box(mid["roi_features"], props, sep_id=sep_id)
         assert got["bbox3d"].shape[0] == wb.shape[0] > 0
         assert np.array_equal(got["labels"].cpu().numpy(), wlab) and set(wlab.tolist()).issubset({1, 2, 3, 4, 5})
-        assert np.array_equal(got["bbox3d"].cpu().numpy(), wb)
-        assert np.allclose(got["scores"].cpu().numpy(), ws, atol=1e-6)
+        gb = got["bbox3d"].cpu().numpy()
+        bad = np.nonzero((gb != wb).any(1))[0]
+        assert len(bad) == 0, (len(bad), bad[:8], gb[bad[:3]], wb[bad[:3]], got["scores"].cpu().numpy()[bad[:3]], ws[bad[:3]])
+        assert np.array_equal(got["scores"].cpu().numpy(), ws)
         for k in ("bbox3d", "scores", "labels"):
             assert torch.equal(got[k], result[k])
 
