@@ -89,15 +89,17 @@ def _nms_sorted(boxes_sorted, thresh, max_keep=0):
     return keep, nk
 
 
-def nms_3d_batched(boxes, order, counts, n_max, iou_threshold, aug_thickness=(0.0, 0.0), max_keep=0):
+def nms_3d_batched(boxes, order, counts, n_max, iou_threshold, aug_thickness=(0.0, 0.0), max_keep=0, segments=1):
     """d3d_rotate_nms_3d_batched: `boxes` [M,7]; segment b's candidates are boxes[order[b, i]], i < counts[b]
-    (order [B, stride] int32 in descending score order; None: one segment = boxes[:n_max] as they are;
-    counts [B] int32 on the device or None) -> keep int32 [B, n_max] (box indices, selection order), n_keep [B]."""
+    (order [B, stride] int32 in descending score order; None: `segments` lists laid out one after the other, segment b =
+    boxes[b * n_max : (b + 1) * n_max] as they are; counts [B] int32 on the device or None) -> keep int32 [B, n_max]
+    (box indices, selection order), n_keep [B]."""
     boxes = _f32c(boxes)
     require_gpu(boxes)
     dev = boxes.device
     if order is None:
-        B, stride = 1, 0
+        B, stride = int(segments), int(n_max)
+        assert boxes.shape[0] >= B * n_max
     else:
         assert order.dtype == torch.int32 and order.is_contiguous() and order.dim() == 2
         B, stride = order.shape
@@ -136,22 +138,71 @@ def nms_3d_presorted(bbox3d, nms_thresh, nms_aug_thickness=None, max_proposals=-
     return keep[0, :int(nk.item())].long()
 
 
-def rotate_nms_3d(rbboxes, scores, pre_max_size=None, post_max_size=None, iou_threshold=0.5, flag=''):
-    """rbboxes [n,7] yx_zb, scores [n] -> LongTensor of kept indices into the input, in score order."""
+def topk_max():
+    return int(lib().d3d_topk_max())
+
+
+def topk_segments(vals, k, n=None, elem_stride=1, group_stride=0, n_groups=1, example=None, n_examples=1, sigmoid=False,
+                  min_value=None, idx_map=None, reg=None, anchors=None, clip=10000.0, want_idx64=True, want_idx32=False):
+    """d3d_topk_segments: the k best elements of every (example, group) segment of `vals` in ONE launch -- descending,
+    equal scores: lower index first (the order the oracle port defines; torch.topk leaves it open).  Element i of group
+    g is vals.view(-1)[g * group_stride + i * elem_stride]; `example` int32 [n] picks the elements of each example.
+    reg [n, >= 7 groups] + anchors [n, 7]: also decode the selected rows (BoxCoder3D.decode, unit weights).
+    -> dict(idx (int64 [S, k]) / idx32, scores [S, k], props [S, k, 7] or None, counts int32 [S]); rows past
+    counts-of-elements are uninitialised.  min_value: counts = kept elements with value > min_value."""
+    require_gpu(vals)
+    assert vals.dtype == torch.float32 and vals.is_contiguous()
+    dev = vals.device
+    if n is None:
+        n = vals.shape[0]
+    S = n_groups * n_examples
+    k = int(k)
+    out = {"idx": torch.empty((S, max(k, 1)), dtype=torch.int64, device=dev) if want_idx64 else None,
+           "idx32": torch.empty((S, max(k, 1)), dtype=torch.int32, device=dev) if want_idx32 else None,
+           "scores": torch.empty((S, max(k, 1)), dtype=torch.float32, device=dev),
+           "props": torch.empty((S, max(k, 1), 7), dtype=torch.float32, device=dev) if reg is not None else None,
+           "counts": torch.empty((S,), dtype=torch.int32, device=dev)}
+    if example is not None:
+        assert example.dtype == torch.int32 and example.is_contiguous() and example.shape[0] == n
+    if reg is not None:
+        require_gpu(reg, anchors)
+        assert reg.dtype == torch.float32 and reg.is_contiguous() and anchors.is_contiguous() and anchors.shape == (n, 7)
+    import ctypes
+    mv = ctypes.byref(ctypes.c_float(float(min_value))) if min_value is not None else None
+    im = _lib.ints(tuple(int(v) for v in idx_map)) if idx_map is not None else None
+    check(lib().d3d_topk_segments(ptr(vals), int(n), int(elem_stride), int(group_stride), int(n_groups), ptr(example),
+                                  int(n_examples), k, int(bool(sigmoid)), mv, im, ptr(reg),
+                                  int(reg.shape[1]) if reg is not None else 0, ptr(anchors), float(clip), ptr(out["idx32"]),
+                                  ptr(out["idx"]), ptr(out["scores"]), ptr(out["props"]), ptr(out["counts"]), stream_of()))
+    return out
+
+
+def rotate_nms_3d(rbboxes, scores, pre_max_size=None, post_max_size=None, iou_threshold=0.5, flag='', aug_thickness=(0.0, 0.0)):
+    """second/pytorch/core/box_torch_ops.py:489-514 through ONE library entry (d3d_rotate_nms_3d): rbboxes [n,7] yx_zb,
+    scores [n] -> LongTensor of kept indices into the input, in score order (equal scores: lower index first).
+    aug_thickness: the size clamp boxlist_nms_3d applies for the IoU only."""
     rbboxes, scores = _f32c(rbboxes), _f32c(scores)
     require_gpu(rbboxes, scores)
-    if rbboxes.shape[0] == 0:
-        return torch.zeros([0], dtype=torch.int64, device=rbboxes.device)
-    k = scores.shape[0] if pre_max_size is None else min(scores.shape[0], pre_max_size)
-    if k > 4096:
-        raise D3DError("rotate_nms_3d: more than 4096 candidates; pass pre_max_size (reference uses 2000)")
-    # descending score order; ties -> lower index first (stable), same rule as the oracle
-    order = torch.sort(scores, descending=True, stable=True)[1][:k]
-    keep, nk = _nms_sorted(rbboxes[order].contiguous(), iou_threshold, post_max_size)
-    n_keep = int(nk.item())
-    if post_max_size is not None:
-        n_keep = min(n_keep, post_max_size)
-    return order[keep[:n_keep].long()]
+    n = rbboxes.shape[0]
+    dev = rbboxes.device
+    if n == 0:
+        return torch.zeros([0], dtype=torch.int64, device=dev)
+    k = n if pre_max_size is None else min(n, int(pre_max_size))
+    if k > topk_max():
+        raise D3DError(f"rotate_nms_3d: more than {topk_max()} candidates; pass pre_max_size (reference uses 2000)")
+    nbytes = lib().d3d_rotate_nms_3d_scratch_bytes(k)
+    buf = _NMS_SCRATCH.get(_nms_key(dev))
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        _NMS_SCRATCH[_nms_key(dev)] = buf
+    keep = torch.empty(k, dtype=torch.int64, device=dev)
+    nk = torch.empty(1, dtype=torch.int32, device=dev)
+    import ctypes
+    n_host = ctypes.c_int(0)
+    check(lib().d3d_rotate_nms_3d(ptr(rbboxes), ptr(scores), n, k, int(post_max_size or 0), float(iou_threshold),
+                                  float(aug_thickness[0]), float(aug_thickness[1]), ptr(keep), ptr(nk),
+                                  ctypes.byref(n_host), ptr(buf), buf.numel(), stream_of()))
+    return keep[:n_host.value]
 
 
 def nms_3d_clamped(bbox3d, scores, nms_thresh, nms_aug_thickness=None, max_proposals=-1, flag=''):
@@ -167,11 +218,8 @@ def nms_3d_clamped(bbox3d, scores, nms_thresh, nms_aug_thickness=None, max_propo
         raise NotImplementedError(flag)
     if max_proposals < 0:
         max_proposals = 500
-    b = bbox3d.clone().detach()
-    b[:, 3:5] = torch.clamp(b[:, 3:5], min=nms_aug_thickness[0])
-    b[:, 5] = torch.clamp(b[:, 5], min=nms_aug_thickness[1])
-    return rotate_nms_3d(b, scores, pre_max_size=2000, post_max_size=max_proposals,
-                         iou_threshold=nms_thresh, flag=flag)
+    return rotate_nms_3d(bbox3d, scores, pre_max_size=2000, post_max_size=max_proposals, iou_threshold=nms_thresh,
+                         flag=flag, aug_thickness=nms_aug_thickness)
 
 
 _UNIT_WEIGHTS = None

@@ -570,23 +570,7 @@ __global__ void k_box_decode(const float *__restrict__ enc, const float *__restr
   // nc > 1: enc holds nc class-wise encodings per anchor row (box_coder_3d.py decode of [n, 7 nc])
   const float *e = enc + src * 7, *a = anchors + (src / (size_t)nc) * 7;
   const float w[7] = {w0, w1, w2, w3, w4, w5, w6};
-  float t[7];
-#pragma unroll
-  for (int k = 0; k < 7; k++) t[k] = e[k] / w[k];
-#pragma unroll
-  for (int k = 3; k < 6; k++) t[k] = fminf(t[k], clip);
-  const float xa = a[0], ya = a[1], za = a[2], wa = a[3], la = a[4], ha = a[5], ra = a[6];
-  const float diagonal = sqrtf(la * la + wa * wa);
-  float *o = out + (size_t)i * 7;
-  o[0] = t[0] * diagonal + xa;
-  o[1] = t[1] * diagonal + ya;
-  o[2] = t[2] * ha + za;
-  o[3] = (t[3] + 1) * wa;
-  o[4] = (t[4] + 1) * la;
-  o[5] = (t[5] + 1) * ha;
-  const float pi = 3.14159265358979323846f;
-  const float rg = t[6] + ra;
-  o[6] = rg - floorf(rg / pi + 0.5f) * pi;
+  box_decode_one(e, a, w, clip, out + (size_t)i * 7);
 }
 
 // survivors of the RPN's NMS into a list padded to P rows: out row i < *n_keep is box / score keep[i] with its sizes
@@ -735,10 +719,6 @@ __global__ __launch_bounds__(256) void k_post_gather(const int32_t *__restrict__
 // the label (box index % nc).  The D-th largest is found by a 4 x 8-bit radix select on the order-preserving integer
 // image of the floats (exact), the compaction by a workgroup scan.
 static constexpr int kSelMax = 8192, kSelThreads = 1024;
-__device__ __forceinline__ uint32_t f32_ordered(float v) {
-  const uint32_t b = __float_as_uint(v);
-  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
 __global__ __launch_bounds__(kSelThreads) void k_post_select(const int32_t *__restrict__ keep,
                                                              const int32_t *__restrict__ nk, int nseg, int n_max,
                                                              const float *__restrict__ prob_flat,

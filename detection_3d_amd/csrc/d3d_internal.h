@@ -123,6 +123,32 @@ struct StridedRaw {  // kept so that the deconvolution plan can be finalised laz
   Size3 out_size;
 };
 
+// order-preserving integer image of a float (larger float <=> larger integer; NaNs above +inf)
+__device__ __forceinline__ uint32_t f32_ordered(float v) {
+  const uint32_t b = __float_as_uint(v);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+// BoxCoder3D.decode of one row (box_coder_3d.py:38-65 / box_torch_ops.py:51-88, smooth_dim): e[7] encoding, a[7] anchor
+// (xa, ya, za, wa, la, ha, ra), w[7] the coder's weights, size deltas clamped to `clip`; yaw wrapped to [-pi/2, pi/2).
+__device__ __forceinline__ void box_decode_one(const float *e, const float *a, const float *w, float clip, float *o) {
+  float t[7];
+#pragma unroll
+  for (int k = 0; k < 7; k++) t[k] = e[k] / w[k];
+#pragma unroll
+  for (int k = 3; k < 6; k++) t[k] = fminf(t[k], clip);
+  const float xa = a[0], ya = a[1], za = a[2], wa = a[3], la = a[4], ha = a[5], ra = a[6];
+  const float diagonal = sqrtf(la * la + wa * wa);
+  o[0] = t[0] * diagonal + xa;
+  o[1] = t[1] * diagonal + ya;
+  o[2] = t[2] * ha + za;
+  o[3] = (t[3] + 1) * wa;
+  o[4] = (t[4] + 1) * la;
+  o[5] = (t[5] + 1) * ha;
+  const float pi = 3.14159265358979323846f;
+  const float rg = t[6] + ra;
+  o[6] = rg - floorf(rg / pi + 0.5f) * pi;
+}
+
 }  // namespace d3d
 
 struct d3d_meta {

@@ -2076,7 +2076,10 @@ static int run_grid_chain(d3d_meta *m, const std::vector<ChainSpec> &specs, hipS
     fs.n16[n_seg] = (bytes + 15) / 16;
     n_seg++;
   };
-  for (int i = 0; i < L; i++) {
+  // A level that cannot be planned (bad sizes, missing input grid, arena exhausted) ends the chain in front of it: the
+  // levels before it are built and published as usual, then its error is returned (what a caller that prepares the
+  // levels one by one would see).
+  auto plan_level = [&](int i) -> int {
     const ChainSpec &sp = specs[i];
     Level &v = lv[i];
     int K = 1, max_out = 1;
@@ -2162,6 +2165,22 @@ static int run_grid_chain(d3d_meta *m, const std::vector<ChainSpec> &specs, hipS
       add_fill(v.nbr_fwd, fwd_bytes);
     }
     made[out_sz] = i;
+    return D3D_OK;
+  };
+  int L_ok = L, fail_rc = D3D_OK;
+  char fail_msg[512] = "";
+  for (int i = 0; i < L; i++) {
+    const size_t used0 = A.used, cap0 = A.cap;
+    const int seg0 = n_seg;
+    if (int rc = plan_level(i)) {
+      A.used = used0;
+      A.cap = cap0;
+      n_seg = seg0;
+      L_ok = i;
+      fail_rc = rc;
+      snprintf(fail_msg, sizeof(fail_msg), "%s", g_err);
+      break;
+    }
   }
   // one fill for every table of every level, then the levels back to back
   if (n_seg > 0) {
@@ -2171,8 +2190,8 @@ static int run_grid_chain(d3d_meta *m, const std::vector<ChainSpec> &specs, hipS
     hipLaunchKernelGGL(k_fill_ones_multi, dim3(bx, n_seg), dim3(256), 0, s, fs);
   }
   CountPtrs cp = {};
-  cp.n = L;
-  for (int i = 0; i < L; i++) {
+  cp.n = L_ok;
+  for (int i = 0; i < L_ok; i++) {
     Level &v = lv[i];
     cp.p[i] = v.n_out_dev;
     if (v.bound_entries == 0) {
@@ -2199,13 +2218,13 @@ static int run_grid_chain(d3d_meta *m, const std::vector<ChainSpec> &specs, hipS
   if (!m->chain_ev) D3D_HIP_CHECK(hipEventCreateWithFlags(&m->chain_ev, hipEventDisableTiming));
   D3D_HIP_CHECK(hipEventRecord(m->chain_ev, s));
   D3D_HIP_CHECK(hipEventSynchronize(m->chain_ev));          // the one read-back of the chain
-  for (int i = 0; i < L; i++) {
+  for (int i = 0; i < L_ok; i++) {
     n_out[i] = ((volatile int32_t *)m->host_counts)[i];
     D3D_REQUIRE(n_out[i] >= 0 && n_out[i] <= lv[i].bound_out, "grid chain: level %d has %d sites, bound %ld", i, n_out[i],
                 lv[i].bound_out);
   }
   // the grids exist: publish them all, then the rulebooks (exact sizes) in order
-  for (int i = 0; i < L; i++) {
+  for (int i = 0; i < L_ok; i++) {
     lv[i].go.n = n_out[i];
     {
       D3D_LOCK(m);
@@ -2213,7 +2232,7 @@ static int run_grid_chain(d3d_meta *m, const std::vector<ChainSpec> &specs, hipS
     }
     if (on_grid) on_grid(hook_arg, i, n_out[i], s);
   }
-  for (int i = 0; i < L; i++) {
+  for (int i = 0; i < L_ok; i++) {
     Level &v = lv[i];
     const ChainSpec &sp = specs[i];
     const int n_in = v.src >= 0 ? n_out[v.src] : v.n_in_host;
@@ -2234,6 +2253,10 @@ static int run_grid_chain(d3d_meta *m, const std::vector<ChainSpec> &specs, hipS
       m->plans.emplace(key, p);
     }
     if (on_done) on_done(hook_arg, i, n_out[i], s);
+  }
+  if (fail_rc != D3D_OK) {
+    set_error("%s", fail_msg);
+    return fail_rc;
   }
   return D3D_OK;
 }

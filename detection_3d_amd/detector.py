@@ -301,13 +301,22 @@ class RPNModule(nn.Module):
     @torch.no_grad()
     def select_proposals(self, objectness, box_regression, anchors, train, defer=False):
         """defer (inference): -> PaddedProposals -- the survivors gathered into `post` rows with their count left on the
-        device, so that the pooler is enqueued behind the NMS without waiting for its read-back."""
+        device, so that the pooler is enqueued behind the NMS without waiting for its read-back.
+        sigmoid -> top-k -> gathers -> decode (inference_3d.py:105-123) are ONE launch (d3d_topk_segments; equal scores:
+        lower anchor index first, the order the oracle port defines)."""
         pre, post = self.top_n[bool(train)]
-        scores = objectness.reshape(-1).sigmoid()
-        k = min(pre, scores.shape[0])
-        scores_k, idx = scores.topk(k, dim=0, sorted=True)                      # inference_3d.py:109
-        if defer and 0 < k <= 2000 and post > 100 and box_regression.shape[1] == 7:
-            proposals = box_ops.box_decode_rows(box_regression, anchors, idx)   # :123, the two gathers inside
+        logits = objectness.reshape(-1).contiguous()
+        k = min(pre, logits.shape[0])
+        reg = box_regression.contiguous()
+        if k == 0 or k > box_ops.topk_max() or reg.shape[1] != 7:
+            scores = logits.sigmoid()
+            order = torch.sort(scores, descending=True, stable=True)[1][:k]    # the same order, in tensor ops
+            scores_k = scores[order]
+            proposals = box_ops.box_decode(reg[order], anchors[order])
+        else:
+            tk = box_ops.topk_segments(logits, k, sigmoid=True, reg=reg, anchors=anchors.contiguous(), want_idx64=False)
+            proposals, scores_k = tk["props"][0, :k], tk["scores"][0, :k]
+        if defer and 0 < k <= 2000 and post > 100:
             keep, nk = box_ops.nms_3d_batched(proposals, None, None, k, self.nms_thresh, self.nms_aug_thickness, post)
             # the survivors, padded to `post` rows, sizes clamped (BoxList3D.clamp_size): one launch, which also
             # stores the count to a pinned word for the host
@@ -315,7 +324,6 @@ class RPNModule(nn.Module):
             boxes, scores_p = box_ops.gather_kept(proposals, scores_k, keep, nk, min(post, k), 0.001, count_host=word)
             stored.record()
             return PaddedProposals(boxes, scores_p, nk, (word, stored))
-        proposals = box_ops.box_decode(box_regression[idx], anchors[idx])       # :123
         keep = box_ops.nms_3d_presorted(proposals, self.nms_thresh, self.nms_aug_thickness, max_proposals=post,
                                         flag='rpn_post')                        # scores_k is sorted: no re-sort
         return proposals[keep], scores_k[keep]
@@ -324,32 +332,25 @@ class RPNModule(nn.Module):
     def select_proposals_segments(self, objectness, box_regression, anchors, example, n_examples, train):
         """RPNPostProcessor.forward_for_single_feature_map (rpn/inference_3d.py:82-163) for every (example, class group)
         pair at once: objectness [n, G], box_regression [n, 7 G], anchors [n, 7], example int64 [n] (None: one example).
-        Segment s = example * G + group gets its own top-k (the other examples' anchors are masked out), one decode
-        launch and one batched NMS serve all segments, ONE read-back returns the survivor counts.
+        Segment s = example * G + group gets its own top-k over the example's anchors; ONE launch selects, gathers and
+        decodes for all segments (d3d_topk_segments), one batched NMS follows, ONE read-back returns the survivor counts.
         -> list over segments of (proposals [m_s, 7], scores [m_s])."""
         pre, post = self.top_n[bool(train)]
         n, G = objectness.shape
         B = int(n_examples)
-        dev = objectness.device
-        scores = objectness.sigmoid().t()                                   # [G, n]
-        if B > 1:
-            member = example.view(1, -1) == torch.arange(B, device=dev).view(-1, 1)     # [B, n]
-            sc = torch.where(member[:, None, :], scores[None], scores.new_full((), -1.0)).reshape(B * G, n)
-            per_example = member.sum(1)
-        else:
-            sc = scores
-            per_example = torch.full((1,), n, dtype=torch.int64, device=dev)
         S = B * G
         k = min(pre, n)
-        sk, idx = sc.topk(k, dim=1, sorted=True)                            # [S, k]: inference_3d.py:109 per segment
-        counts = per_example.clamp(max=k).view(B, 1).expand(B, G).reshape(S).to(torch.int32).contiguous()
-        group_of = torch.arange(G, device=dev).repeat(B).view(S, 1)
-        reg = box_regression.view(n, G, 7)[idx, group_of]                   # [S, k, 7]
-        flat = idx.reshape(-1)
-        props = box_ops.box_decode(reg.reshape(-1, 7), anchors[flat])       # :123
-        order = torch.arange(S * k, dtype=torch.int32, device=dev).view(S, k)
-        keep, nk = box_ops.nms_3d_batched(props, order, counts, k, self.nms_thresh, self.nms_aug_thickness, post)
-        sk = sk.reshape(-1)
+        if k == 0:
+            z = anchors.new_zeros
+            return [(z((0, 7)), z((0,))) for _ in range(S)]
+        assert k <= box_ops.topk_max(), k
+        ex32 = example.to(torch.int32).contiguous() if B > 1 else None
+        tk = box_ops.topk_segments(objectness.contiguous(), k, n=n, elem_stride=G, group_stride=1, n_groups=G, example=ex32,
+                                   n_examples=B, sigmoid=True, reg=box_regression.contiguous(),
+                                   anchors=anchors.contiguous(), want_idx64=False)
+        props, sk = tk["props"].view(-1, 7), tk["scores"].reshape(-1)             # [S k, 7]: inference_3d.py:109-123
+        keep, nk = box_ops.nms_3d_batched(props, None, tk["counts"], k, self.nms_thresh, self.nms_aug_thickness, post,
+                                          segments=S)
         out = []
         for s_, m in enumerate(nk.tolist()):                                # the one host synchronisation
             sel = keep[s_, :m].long()
@@ -643,13 +644,20 @@ class PostProcessor(nn.Module):
         # descending score order (ties: lower RoI first) are a segment of box indices roi*nc + j; the glue around the
         # sort, the NMS and the top-k is three library launches (d3d_post_*), bit-identical to _select_reference
         dev, prob = prob.device, prob.contiguous()
-        sc = torch.empty((nc - 1, K), dtype=torch.float32, device=dev)
-        counts = torch.empty((nc - 1,), dtype=torch.int32, device=dev)
-        check(lib().d3d_post_scores(ptr(prob), K, nc, float(self.score_thresh), ptr(sc), ptr(counts), stream_of()))
-        idx = torch.sort(sc, dim=1, descending=True, stable=True)[1]
-        order = torch.empty((nc - 1, K), dtype=torch.int32, device=dev)
-        check(lib().d3d_post_order(ptr(idx), K, nc, ptr(order), stream_of()))
         n_max = min(K, 2000)                                                     # pre_max_size of rotate_nms_3d
+        if n_max <= box_ops.topk_max():
+            # class j's list = the RoIs with prob[:, j] > thresh, best first (equal scores: lower RoI first), as box
+            # indices roi * nc + j: one launch (d3d_topk_segments over the nc - 1 foreground columns)
+            tk = box_ops.topk_segments(prob.view(-1)[1:], n_max, n=K, elem_stride=nc, group_stride=1, n_groups=nc - 1,
+                                       min_value=self.score_thresh, idx_map=(nc, 1, 1), want_idx64=False, want_idx32=True)
+            order, counts = tk["idx32"], tk["counts"]
+        else:
+            sc = torch.empty((nc - 1, K), dtype=torch.float32, device=dev)
+            counts = torch.empty((nc - 1,), dtype=torch.int32, device=dev)
+            check(lib().d3d_post_scores(ptr(prob), K, nc, float(self.score_thresh), ptr(sc), ptr(counts), stream_of()))
+            idx = torch.sort(sc, dim=1, descending=True, stable=True)[1]
+            order = torch.empty((nc - 1, K), dtype=torch.int32, device=dev)
+            check(lib().d3d_post_order(ptr(idx), K, nc, ptr(order), stream_of()))
         keep, nk = box_ops.nms_3d_batched(boxes.view(-1, 7), order, counts, n_max, self.nms, self.nms_aug_thickness,
                                           500)                                   # post_max_size (boxlist_ops_3d.py)
         N = (nc - 1) * n_max
@@ -672,7 +680,7 @@ class PostProcessor(nn.Module):
         check(lib().d3d_post_gather(ptr(keep), ptr(nk), nc - 1, n_max, ptr(prob), ptr(s_all), ptr(flat_all), stream_of()))
         if 0 < self.detections_per_img < s_all.shape[0]:                         # :140-148 without a second read-back:
             # the D-th largest score; with fewer than D survivors it is a padding entry (-1) and every survivor stays
-            thresh = torch.topk(s_all, self.detections_per_img, sorted=True)[0][-1]
+            thresh = torch.sort(s_all, descending=True)[0][self.detections_per_img - 1]
             sel = s_all >= thresh.clamp_min(0.0)                                 # survivors have scores > 0, padding -1
         else:
             sel = s_all >= 0.0
@@ -714,19 +722,27 @@ class PostProcessor(nn.Module):
         member = seg_id.view(1, -1) == torch.arange(S, device=dev).view(-1, 1)                            # [S, K]
         p = prob[:, 1:].t()                                                                               # [cmax-1, K]
         cand = (p > self.score_thresh)[None] & member[:, None, :]                                         # [S, cmax-1, K]
-        sc = torch.where(cand, p[None], p.new_full((), -1.0)).reshape(nseg, K)
-        idx = torch.sort(sc, dim=1, descending=True, stable=True)[1]
+        sc = torch.where(cand, p[None], p.new_full((), -1.0)).reshape(nseg, K).contiguous()
         n_max = max(1, min(max(seg_sizes), 2000))                                                         # pre_max_size
-        slot = (torch.arange(cmax - 1, device=dev) + 1).repeat(S).view(nseg, 1)
-        order = (idx[:, :n_max] * cmax + slot).to(torch.int32).contiguous()
-        counts = cand.reshape(nseg, K).sum(1).clamp(max=n_max).to(torch.int32)
+        assert n_max <= box_ops.topk_max()
+        # every (segment, class) row's candidates, best first (equal scores: lower row first): one launch
+        tk = box_ops.topk_segments(sc, n_max, n=K, elem_stride=1, group_stride=K, n_groups=nseg, min_value=self.score_thresh,
+                                   want_idx64=False, want_idx32=True)
+        slot = (torch.arange(cmax - 1, device=dev, dtype=torch.int32) + 1).repeat(S).view(nseg, 1)
+        order = (tk["idx32"] * cmax + slot).contiguous()
+        counts = tk["counts"]
         keep, nk = box_ops.nms_3d_batched(boxes.view(-1, 7), order, counts, n_max, self.nms, self.nms_aug_thickness, 500)
         valid = torch.arange(n_max, device=dev).view(1, -1) < nk.view(-1, 1)                              # [nseg, n_max]
         flat = torch.where(valid, keep, torch.zeros_like(keep)).long()                                    # row * cmax + slot
         s_all = torch.where(valid, prob.reshape(-1)[flat], prob.new_full((), -1.0)).view(S, -1)
         valid, flat = valid.view(S, -1), flat.view(S, -1)
         if 0 < self.detections_per_img < s_all.shape[1]:                                                 # :140-148 per segment
-            thresh = torch.topk(s_all, self.detections_per_img, dim=1, sorted=True)[0][:, -1]
+            if self.detections_per_img <= box_ops.topk_max():
+                top = box_ops.topk_segments(s_all.contiguous(), self.detections_per_img, n=s_all.shape[1], elem_stride=1,
+                                            group_stride=s_all.shape[1], n_groups=S, want_idx64=False)["scores"]
+                thresh = top[:, self.detections_per_img - 1]
+            else:
+                thresh = torch.sort(s_all, dim=1, descending=True)[0][:, self.detections_per_img - 1]
             sel = valid & (s_all >= thresh.view(-1, 1))
         else:
             sel = valid
@@ -754,7 +770,7 @@ class PostProcessor(nn.Module):
         flat_all = torch.where(valid, keep, torch.zeros_like(keep)).long().view(-1)   # class-major, selection order
         s_all = torch.where(valid.view(-1), prob.reshape(-1)[flat_all], prob.new_full((), -1.0))
         if 0 < self.detections_per_img < s_all.shape[0]:
-            thresh = torch.topk(s_all, self.detections_per_img, sorted=True)[0][-1]
+            thresh = torch.sort(s_all, descending=True)[0][self.detections_per_img - 1]
             sel = valid.view(-1) & (s_all >= thresh)
         else:
             sel = valid.view(-1)

@@ -398,6 +398,34 @@ int d3d_rotate_nms_3d_batched(const float *boxes, const int32_t *order, int stri
                               int segments, int n_max, float thresh, float min_yx, float min_z,
                               int max_keep, int32_t *keep, int32_t *n_keep, void *scratch,
                               size_t scratch_bytes, void *stream);
+/* a15. rotate_nms_3d AS THE REFERENCE DEFINES IT (second/pytorch/core/box_torch_ops.py:489-514, called by
+ * boxlist_nms_3d, structures/boxlist_ops_3d.py:14-62, with its size clamp): boxes [n,7] yx_zb and scores [n] in any order.
+ * Candidates = the pre_max_size best scores (<= 0: all; at most d3d_topk_max()); descending score, and among EQUAL scores
+ * the lower index first -- torch.topk / numpy argsort (nms_cpu.py:37) leave that order open, here and in the oracle port
+ * it is defined.  Sizes clamped for the IoU only (dy, dx >= aug_yx, dz >= aug_z); greedy rotated NMS at `thresh`; at
+ * most post_max_size survivors (<= 0: all).  keep_out int64 [min(n, pre_max_size)] = indices into the input in selection
+ * order (the LongTensor the reference returns); n_keep_dev device int32 [1]; n_keep_host (NULL: no read-back) receives
+ * the count after one stream synchronisation.  scratch >= d3d_rotate_nms_3d_scratch_bytes(pre_max_size).            */
+int d3d_rotate_nms_3d(const float *boxes, const float *scores, int n, int pre_max_size, int post_max_size, float thresh,
+                      float aug_yx, float aug_z, int64_t *keep_out, int32_t *n_keep_dev, int *n_keep_host, void *scratch,
+                      size_t scratch_bytes, void *stream);
+size_t d3d_rotate_nms_3d_scratch_bytes(int pre_max_size);
+/* a13. The selection of RPNPostProcessor.forward_for_single_feature_map (modeling/rpn/inference_3d.py:105-123), and of
+ * the per-class candidate lists of the box head's post-processing (roi_heads/box_head_3d/inference.py:113-131), for
+ * n_examples x n_groups segments in ONE launch.  Segment s = example * n_groups + group reads element i at
+ * vals[group * group_stride + i * elem_stride] (apply_sigmoid: 1 / (1 + exp(-x)) first, inference_3d.py:105) over the
+ * elements with example[i] == its example (example NULL when n_examples == 1), keeps the k best (k <= d3d_topk_max();
+ * descending, equal scores: lower index first) and writes rows [s * k, s * k + min(k, elements)) of the outputs: element
+ * indices (idx32_out = i * idx_map[0] + idx_map[1] + group * idx_map[2], idx_map_host NULL: i; idx64_out = i), scores
+ * and -- when props_out is given -- the decoded boxes BoxCoder3D.decode(reg[i * reg_stride + 7 group .. + 7],
+ * anchors[i]) with unit weights (box_coder_3d.py:38-65, inference_3d.py:123).  counts_out int32 [segments] =
+ * min(k, elements of the segment), or with min_value_host the number of kept elements with value > *min_value_host
+ * (the score threshold of inference.py:118; a prefix of the sorted list).  Outputs other than counts_out may be NULL. */
+int d3d_topk_segments(const float *vals, int n, int elem_stride, int group_stride, int n_groups, const int32_t *example,
+                      int n_examples, int k, int apply_sigmoid, const float *min_value_host, const int *idx_map_host,
+                      const float *reg, int reg_stride, const float *anchors, float clip, int32_t *idx32_out,
+                      int64_t *idx64_out, float *scores_out, float *props_out, int32_t *counts_out, void *stream);
+int d3d_topk_max(void);
 size_t d3d_nms_batched_scratch_bytes(int segments, int n_max);
 /* Box-head post-processing glue around the batched NMS (roi_heads/box_head_3d/inference.py:113-148), one launch each:
  * post_scores: sc[(nc-1), K] = prob[i][j+1] if > thresh else -1 (class-major), counts[nc-1] = candidates per class

@@ -293,3 +293,94 @@ def test_decode_of_selected_rows_and_padded_survivor_list(dev):
         pad = boxes[0].clone()
         pad[3:6] = torch.clamp(pad[3:6], min=0.001)
         assert bool((ob[nk:] == pad).all()) and bool((os_[nk:] == scores[0]).all())
+
+
+def _stable_topk(v, k):
+    """descending, equal values: lower index first"""
+    return np.argsort(-v.astype(np.float64), kind="stable")[:k]
+
+
+@pytest.mark.parametrize("n,k", [(1, 5), (100, 100), (5000, 2000), (160_000, 2000), (160_000, 4096), (70_001, 1000)])
+def test_topk_order_is_the_defined_one(dev, n, k):
+    """d3d_topk_segments: exactly the k best in descending order with ties broken by the lower index -- on scores full of
+    ties, incl. saturated sigmoids (== 1.0) and a threshold that falls inside a run of equal values."""
+    from detection_3d_amd import box_ops
+    rng = np.random.RandomState(n + k)
+    logits = (rng.randn(n) * 4).astype(np.float32)
+    logits[rng.rand(n) < 0.02] = 40.0                      # sigmoid saturates to exactly 1.0
+    logits[rng.rand(n) < 0.30] = np.float32(0.37)          # a long run of equal values (the k-th falls into it for large k)
+    t = torch.from_numpy(logits).to(dev)
+    for sig in (False, True):
+        tk = box_ops.topk_segments(t, k, sigmoid=sig)
+        vals = torch.sigmoid(t).cpu().numpy() if sig else logits
+        want = _stable_topk(vals, k)
+        m = int(tk["counts"][0])
+        assert m == min(k, n)
+        got = tk["idx"][0, :m].cpu().numpy()
+        if sig:     # the kernel's own sigmoid defines its order: check against ITS values, and those against torch's
+            own = box_ops.topk_segments(t, min(n, 4096), sigmoid=True)
+            full = np.empty(n, np.float32)
+            if n <= 4096:
+                full[own["idx"][0, :n].cpu().numpy()] = own["scores"][0, :n].cpu().numpy()
+                assert np.array_equal(full, vals)          # same formula, IEEE division: the same bits as torch.sigmoid
+        assert np.array_equal(got, want), (n, k, sig, np.nonzero(got != want)[0][:5])
+        assert np.array_equal(tk["scores"][0, :m].cpu().numpy(), vals[want])
+    assert (np.sort(vals)[::-1][:k] == 1.0).sum() >= min(k, int((logits == 40.0).sum()))
+
+
+def test_topk_segments_groups_examples_threshold_and_decode(dev):
+    """the RPN layout (columns = class groups, example index per element) with the decode fused in, and the box head's
+    layout (row-major segments, score threshold count, mapped indices)"""
+    from detection_3d_amd import box_ops
+    rng = np.random.RandomState(11)
+    n, G, B, k = 30_000, 3, 2, 1000
+    obj = (rng.randn(n, G) * 3).astype(np.float32)
+    obj[::5] = 25.0
+    reg = (rng.randn(n, 7 * G) * 0.2).astype(np.float32)
+    anchors = np.concatenate([rng.rand(n, 3) * 20, 0.2 + rng.rand(n, 3) * 3, (rng.rand(n, 1) - 0.5) * 3], 1).astype(np.float32)
+    ex = np.sort(rng.randint(0, B, n)).astype(np.int32)
+    ex[-7:] = 0                                              # not contiguous per example
+    tk = box_ops.topk_segments(torch.from_numpy(obj).to(dev), k, n=n, elem_stride=G, group_stride=1, n_groups=G,
+                               example=torch.from_numpy(ex).to(dev), n_examples=B, sigmoid=True,
+                               reg=torch.from_numpy(reg).to(dev), anchors=torch.from_numpy(anchors).to(dev))
+    sig = torch.sigmoid(torch.from_numpy(obj).to(dev)).cpu().numpy()
+    for b in range(B):
+        rows = np.nonzero(ex == b)[0]
+        for g in range(G):
+            s_ = b * G + g
+            want = rows[_stable_topk(sig[rows, g], k)]
+            assert int(tk["counts"][s_]) == len(want) == k
+            assert np.array_equal(tk["idx"][s_].cpu().numpy(), want)
+            assert np.array_equal(tk["props"][s_].cpu().numpy(), oracle.box_decode(reg[want, 7 * g:7 * g + 7], anchors[want]))
+    # box-head layout: nseg rows of K scores, candidates = scores > 0.05, indices mapped to idx * nc + 1 + g
+    K, nc = 1000, 4
+    prob = rng.rand(K, nc).astype(np.float32)
+    prob[:, 2] = np.where(rng.rand(K) < 0.5, np.float32(0.5), prob[:, 2])       # ties
+    prob[:, 3] *= 0.04                                                            # nothing above the threshold
+    t = torch.from_numpy(prob).to(dev)
+    tk = box_ops.topk_segments(t.view(-1)[1:], K, n=K, elem_stride=nc, group_stride=1, n_groups=nc - 1, min_value=0.05,
+                               idx_map=(nc, 1, 1), want_idx64=False, want_idx32=True)
+    for j in range(1, nc):
+        cnt = int((prob[:, j] > 0.05).sum())
+        assert int(tk["counts"][j - 1]) == cnt
+        want = _stable_topk(prob[:, j], K)[:cnt]
+        assert np.array_equal(tk["idx32"][j - 1, :cnt].cpu().numpy(), want * nc + j)
+    assert int(tk["counts"][2]) == 0 and int(tk["counts"][1]) > 400
+    # empty input
+    e = box_ops.topk_segments(torch.zeros(0, device=dev), 10)
+    assert int(e["counts"][0]) == 0
+
+
+@pytest.mark.parametrize("n,pre,post", [(5000, 2000, 1000), (300, 2000, 100), (2500, 1000, 0)])
+def test_rotate_nms_3d_reference_shaped_entry(dev, n, pre, post):
+    """d3d_rotate_nms_3d(boxes, scores, pre, post, thr, aug_yx, aug_z): unsorted input, top-k with the defined tie order,
+    size clamp for the IoU only, survivor indices into the INPUT -- against the oracle's boxlist_nms_3d (nms_clamped)."""
+    from detection_3d_amd import box_ops
+    from oracle.detector_port import nms_clamped
+    b, s = make_boxes(77 + n, n)
+    s[::5] = s[2]                                            # ties
+    s[1::9] = 1.0                                            # saturated
+    got = box_ops.rotate_nms_3d(torch.from_numpy(b).to(dev), torch.from_numpy(s).to(dev), pre, post or None, 0.5,
+                                aug_thickness=(0.3, 0.25)).cpu().numpy()
+    want = nms_clamped(b, s, 0.5, (0.3, 0.25), post if post else n, pre_max=pre)
+    assert np.array_equal(got, want) and 0 < len(got) <= (post or n)
