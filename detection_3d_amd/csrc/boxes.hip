@@ -560,6 +560,147 @@ __global__ __launch_bounds__(64) void k_nms_sweep(const unsigned long long *__re
   if (lane == 0) *n_keep = min(cnt, max_keep);  // the last chunk may overshoot the cap
 }
 
+// The same sweep with the mask rows staged through LDS by loader waves.  k_nms_sweep keeps three chunks of 64 rows in
+// registers (384 VGPRs; the compiler moves them through the accumulation registers and scratch) and spends ~3.4 us per
+// 64-box chunk, almost all of it waiting: the dependent chain itself is ~0.15 us.  Here the workgroup is one sweeper wave
+// and kSwLoaders loader waves: a loader thread holds its 16-byte pieces of the next kSwStages chunks in registers (loads
+// issued that many iterations ahead, so their latency is covered) and drops the oldest into one of two LDS slots while the
+// sweeper works on the other; one workgroup barrier per chunk hands the slots over.  The sweeper reads its 64 diagonal
+// words and, for the update of the removed set, the rows of the chunk from LDS (static offsets, conflict-free row
+// stride of ncb + 1 words).  Same decisions in the same order: identical survivor lists.
+static constexpr int kSwLoaders = 4, kSwStages = 4;
+static constexpr int kSwThreads = 64 * (1 + kSwLoaders);
+template <int NCBMAX>   // words per mask row <= NCBMAX (16: n <= 1024, 32: n <= 2048, 64: n <= 4096)
+__global__ __launch_bounds__(kSwThreads) void k_nms_sweep_lds(const unsigned long long *__restrict__ mask, NmsSegs g,
+                                                              int ncb, int max_keep, int32_t *__restrict__ keep,
+                                                              int32_t *__restrict__ n_keep) {
+  constexpr int NP = NCBMAX * 32 / (64 * kSwLoaders);      // 16-byte pieces of a chunk per loader thread
+  static_assert(NP >= 1, "a chunk must give every loader thread a piece");
+  extern __shared__ unsigned long long slots[];             // 2 x 64 rows x (ncb + 1) words
+  __shared__ int stop_s;
+  const int sb = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = seg_count(g, sb);
+  mask += (size_t)sb * g.n_max * ncb;
+  keep += (size_t)sb * g.n_max;
+  n_keep += sb;
+  const int ncw = (n + 63) / 64;
+  const int rs = ncb + 1;                                    // LDS row stride in words
+  const int slot_words = 64 * rs;
+  if (threadIdx.x == 0) stop_s = 0;
+  if (ncw == 0) {
+    if (threadIdx.x == 0) *n_keep = 0;
+    return;
+  }
+  const int half = ncb / 2 + (ncb & 1);                      // 16-byte pieces per row (the last may be half used)
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  // ---- loader side: piece p of thread tl covers words [2 q % half .., +2) of row q / half, q = tl + 64 kSwLoaders p
+  const int tl = (int)threadIdx.x - 64;
+  u64x2 st[kSwStages][NP];
+  auto issue = [&](int c, u64x2 *dst) {                      // global loads of chunk c -> registers
+    if (c >= ncw) return;
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+      const int q = tl + 64 * kSwLoaders * p;
+      const int row = q / half, w2 = (q - row * half) * 2;
+      u64x2 v = {0ull, 0ull};
+      if (row < 64) {
+        const unsigned long long *src = mask + (size_t)min(c * 64 + row, n - 1) * ncb + w2;
+        v[0] = src[0];
+        if (w2 + 1 < ncb) v[1] = src[1];
+      }
+      dst[p] = v;
+    }
+  };
+  auto drop = [&](int c, const u64x2 *src) {                 // registers -> LDS slot c & 1
+    if (c >= ncw) return;
+    unsigned long long *slot = slots + (size_t)(c & 1) * slot_words;
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+      const int q = tl + 64 * kSwLoaders * p;
+      const int row = q / half, w2 = (q - row * half) * 2;
+      if (row < 64) {
+        slot[row * rs + w2] = src[p][0];
+        if (w2 + 1 < ncb) slot[row * rs + w2 + 1] = src[p][1];
+      }
+    }
+  };
+  // ---- sweeper state
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  unsigned long long removed = 0;                            // word `lane` of the removed set
+  int cnt = 0;
+  if (wave > 0) {
+#pragma unroll
+    for (int j = 0; j < kSwStages; j++) issue(j, st[j]);
+    drop(0, st[0]);
+    issue(kSwStages, st[0]);
+  }
+  __syncthreads();
+  for (int c0 = 0; c0 < ncw; c0 += kSwStages) {
+    bool stop = false;
+#pragma unroll
+    for (int u = 0; u < kSwStages; u++) {
+      const int c = c0 + u;
+      if (c >= ncw) break;                                   // uniform
+      if (wave > 0) {
+        // chunk c + 1 (loaded kSwStages - 1 iterations ago) goes to the other slot; its stage is refilled
+        drop(c + 1, st[(u + 1) % kSwStages]);
+        issue(c + 1 + kSwStages, st[(u + 1) % kSwStages]);
+      } else {
+        const unsigned long long *slot = slots + (size_t)(c & 1) * slot_words;
+        const int base = c * 64;
+        const int nrow = min(64, n - base);
+        const int my_box = lane < nrow ? seg_box(g, sb, base + lane) : 0;
+        const unsigned long long diag = lane < nrow ? slot[lane * rs + c] : 0ull;
+        unsigned long long alive =
+            ~(((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(removed >> 32), c) << 32) |
+              (unsigned int)__builtin_amdgcn_readlane((int)removed, c));
+        if (nrow < 64) alive &= (1ull << nrow) - 1ull;
+        unsigned long long kept = 0;
+        const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
+#pragma unroll
+        for (int part = 0; part < 4; part++) {
+          unsigned long long d[16];
+#pragma unroll
+          for (int b = 0; b < 16; b++)
+            d[b] = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, part * 16 + b) << 32) |
+                   (unsigned int)__builtin_amdgcn_readlane((int)dlo, part * 16 + b);
+#pragma unroll
+          for (int b = 0; b < 16; b++) {
+            const unsigned long long bit = 1ull << (part * 16 + b);
+            const bool on = (alive & bit) != 0;
+            kept |= on ? bit : 0ull;
+            alive &= on ? ~d[b] : ~0ull;
+          }
+        }
+        // removed |= rows of the kept boxes (word `lane`): 16 LDS reads in flight at a time
+        const unsigned long long *col = slot + min(lane, ncb - 1);
+#pragma unroll
+        for (int part = 0; part < 4; part++) {
+          unsigned long long w[16];
+#pragma unroll
+          for (int b = 0; b < 16; b++) w[b] = col[(part * 16 + b) * rs];
+#pragma unroll
+          for (int b = 0; b < 16; b++)
+            if ((kept >> (part * 16 + b)) & 1ull) removed |= w[b];
+        }
+        if ((kept >> lane) & 1ull) {
+          const int pos = cnt + __popcll(kept & lt);
+          if (pos < g.n_max) keep[pos] = my_box;
+        }
+        cnt += __popcll(kept);
+        if (cnt >= max_keep && lane == 0) stop_s = 1;
+      }
+      __syncthreads();
+      if (stop_s) {
+        stop = true;
+        break;
+      }
+    }
+    if (stop) break;
+  }
+  if (threadIdx.x == 0) *n_keep = min(cnt, max_keep);
+}
+
 // a14. BoxCoder3D.decode
 __global__ void k_box_decode(const float *__restrict__ enc, const float *__restrict__ anchors, int n,
                              float w0, float w1, float w2, float w3, float w4, float w5, float w6,
@@ -666,7 +807,22 @@ int d3d_rotate_nms_3d_batched(const float *boxes, const int32_t *order, int stri
   hipLaunchKernelGGL(k_nms_prep, dim3((n + 127) / 128, B), dim3(128), 0, s, boxes, g, min_yx, min_z, rec);
   hipLaunchKernelGGL(k_nms_pairs, dim3(ncb, ncb, B), dim3(256), 0, s, rec, g, pairs, n_pairs);
   hipLaunchKernelGGL(k_nms_eval, dim3(1024), dim3(kEvalThreads), 0, s, rec, pairs, n_pairs, n, ncb, thresh, mask);
-  hipLaunchKernelGGL(k_nms_sweep, dim3(B), dim3(64), 0, s, mask, g, ncb, max_keep > 0 ? max_keep : n, keep, n_keep);
+  const int mk = max_keep > 0 ? max_keep : n;
+  static const bool lds_sweep = [] {      // D3D_NMS_SWEEP=regs: the single-wave form (A/B runs)
+    const char *e = getenv("D3D_NMS_SWEEP");
+    return !(e && e[0] == 'r');
+  }();
+  if (lds_sweep) {
+    const size_t lds = (size_t)2 * 64 * (ncb + 1) * sizeof(unsigned long long);
+    if (ncb <= 16)
+      hipLaunchKernelGGL(k_nms_sweep_lds<16>, dim3(B), dim3(kSwThreads), lds, s, mask, g, ncb, mk, keep, n_keep);
+    else if (ncb <= 32)
+      hipLaunchKernelGGL(k_nms_sweep_lds<32>, dim3(B), dim3(kSwThreads), lds, s, mask, g, ncb, mk, keep, n_keep);
+    else
+      hipLaunchKernelGGL(k_nms_sweep_lds<64>, dim3(B), dim3(kSwThreads), lds, s, mask, g, ncb, mk, keep, n_keep);
+  } else {
+    hipLaunchKernelGGL(k_nms_sweep, dim3(B), dim3(64), 0, s, mask, g, ncb, mk, keep, n_keep);
+  }
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }

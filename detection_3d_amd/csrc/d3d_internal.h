@@ -79,6 +79,8 @@ struct Grid {
   HashEntry *tab = nullptr;
   int32_t *loc = nullptr;  // [n,4] x,y,z,b
   int32_t *extent = nullptr;  // device int[3]: 1 + max coordinate per axis (filled on first use, grid_extent)
+  int hext[4] = {0, 0, 0, 0};  // host-side UPPER BOUNDS of 1 + max x, y, z, example index (0: unknown); bound the site counts
+                               // of the grids built from this one (grid chain)
 };
 
 // BatchNorm affine + leaky ReLU on 4 channels: y = leaky(fma(x, w, b)).  ONE definition for k_bn_apply and the fused

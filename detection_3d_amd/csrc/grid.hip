@@ -1636,6 +1636,7 @@ int d3d_input_layer_build_prefetch(d3d_meta *m, const int64_t *coords, int n, in
     A.used = mark;
   }
   g.n = n_active;
+  for (int d = 0; d < 4; d++) g.hext[d] = m->in_ext[d];
   m->in_active = n_active;
   {
     D3D_LOCK(m);
@@ -2120,9 +2121,9 @@ static int run_grid_chain(d3d_meta *m, const std::vector<ChainSpec> &specs, hipS
       v.loc_in = gi->loc;
       v.n_in_host = gi->n;
       v.bound_in = gi->n;
-      const bool is_input = in_sz == m->in_size && m->in_ext[0] > 0;
-      for (int d = 0; d < 3; d++) ext_in[d] = is_input ? m->in_ext[d] : sp.in_size[d];
-      ext_in[3] = is_input ? m->in_ext[3] : 0;        // 0: number of examples unknown -> no cell bound
+      const bool known = gi->hext[0] > 0 && gi->hext[3] > 0;
+      for (int d = 0; d < 3; d++) ext_in[d] = known ? gi->hext[d] : sp.in_size[d];
+      ext_in[3] = known ? gi->hext[3] : 0;            // 0: number of examples unknown -> no cell bound
     }
     v.bound_entries = v.bound_in * max_out;
     long cells = ext_in[3] > 0 ? ext_in[3] : -1;
@@ -2226,6 +2227,7 @@ static int run_grid_chain(d3d_meta *m, const std::vector<ChainSpec> &specs, hipS
   // the grids exist: publish them all, then the rulebooks (exact sizes) in order
   for (int i = 0; i < L_ok; i++) {
     lv[i].go.n = n_out[i];
+    for (int d = 0; d < 4; d++) lv[i].go.hext[d] = lv[i].ext_out[d];
     {
       D3D_LOCK(m);
       m->grids[Size3{specs[i].out_size[0], specs[i].out_size[1], specs[i].out_size[2]}] = lv[i].go;
@@ -2261,13 +2263,18 @@ static int run_grid_chain(d3d_meta *m, const std::vector<ChainSpec> &specs, hipS
   return D3D_OK;
 }
 
-// D3D_GRID_CHAIN=0: one d3d_conv_prepare (and read-back) per level, for A/B runs
-static const bool g_chain_enabled = [] {
+// D3D_GRID_CHAIN=0 (or d3d_grid_chain_enable(0)): one d3d_conv_prepare (and read-back) per level, for A/B runs
+static bool g_chain_enabled = [] {
   const char *e = getenv("D3D_GRID_CHAIN");
   return !(e && e[0] == '0');
 }();
 
-static void geo_run_grids(d3d_meta *m, GeoAsync *g) {      // the grids of the chain; ONE read-back for all of them
+static int g_chain_head = [] {
+  const char *e = getenv("D3D_GRID_CHAIN_HEAD");
+  return e ? atoi(e) : 1;
+}();
+
+static void geo_run_grids(d3d_meta *m, GeoAsync *g) {      // the grids of the pyramid: two chains, two read-backs
   int rc = geo_begin(g);
   const int n = (int)g->specs.size();
   std::vector<int> rows;
@@ -2278,7 +2285,8 @@ static void geo_run_grids(d3d_meta *m, GeoAsync *g) {      // the grids of the c
     GeoAsync *g;
     const std::vector<int> *rows;
     bool failed;
-  } hk = {g, &rows, false};
+    int first;                              // row of `rows` the running chain's level 0 is
+  } hk = {g, &rows, false, 0};
   if (g_chain_enabled && rc == D3D_OK) {
     std::vector<ChainSpec> specs(rows.size());
     for (size_t j = 0; j < rows.size(); j++) {
@@ -2291,28 +2299,35 @@ static void geo_run_grids(d3d_meta *m, GeoAsync *g) {      // the grids of the c
       }
       specs[j].need_dec = g->specs[rows[j]][0] == 1;      // kind 3: a strided grid whose decoded table nobody will ask for
     }
-    std::vector<int> n_out;
-    rc = run_grid_chain(
-        m, specs, g->stream, n_out,
-        [](void *a, int level, int, hipStream_t on) {       // the grid exists: its submanifold views may start
-          Hook *h = (Hook *)a;
-          const int i = (*h->rows)[level];
-          if (hipEventRecord(h->g->gev[i], on) != hipSuccess) return;
-          std::lock_guard<std::mutex> lk(h->g->mu);
-          h->g->grid_ready[i] = 1;
-          h->g->cv.notify_all();
-        },
-        [](void *a, int level, int n_sites, hipStream_t on) {   // its strided rulebook is enqueued
-          Hook *h = (Hook *)a;
-          const int i = (*h->rows)[level];
-          int rc2 = D3D_OK;
-          if (hipEventRecord(h->g->ev[i], on) != hipSuccess) {
-            set_error("geometry thread: hipEventRecord failed");
-            rc2 = D3D_ERR_HIP;
-          }
-          if (!geo_publish(h->g, i, rc2, n_sites)) h->failed = true;
-        },
-        &hk);
+    // Two chains: the first level alone -- the feature pass wants it (and its rulebooks) a few hundred microseconds after
+    // the input grid, before a chain over all levels has finished -- then every other level in one go.
+    const ChainHook on_grid = [](void *a, int level, int, hipStream_t on) {       // the grid exists: its views may start
+      Hook *h = (Hook *)a;
+      const int i = (*h->rows)[h->first + level];
+      if (hipEventRecord(h->g->gev[i], on) != hipSuccess) return;
+      std::lock_guard<std::mutex> lk(h->g->mu);
+      h->g->grid_ready[i] = 1;
+      h->g->cv.notify_all();
+    };
+    const ChainHook on_done = [](void *a, int level, int n_sites, hipStream_t on) {   // its strided rulebook is enqueued
+      Hook *h = (Hook *)a;
+      const int i = (*h->rows)[h->first + level];
+      int rc2 = D3D_OK;
+      if (hipEventRecord(h->g->ev[i], on) != hipSuccess) {
+        set_error("geometry thread: hipEventRecord failed");
+        rc2 = D3D_ERR_HIP;
+      }
+      if (!geo_publish(h->g, i, rc2, n_sites)) h->failed = true;
+    };
+    const size_t cut = std::min<size_t>(g_chain_head, specs.size());
+    for (int part = 0; part < 2 && rc == D3D_OK && !hk.failed; part++) {
+      const size_t lo = part == 0 ? 0 : cut, hi = part == 0 ? cut : specs.size();
+      if (lo >= hi) continue;
+      std::vector<ChainSpec> seg(specs.begin() + lo, specs.begin() + hi);
+      std::vector<int> n_out;
+      hk.first = (int)lo;
+      rc = run_grid_chain(m, seg, g->stream, n_out, on_grid, on_done, &hk);
+    }
     if (rc != D3D_OK) geo_publish(g, rows[0], rc, 0);
     return;
   }
@@ -2377,6 +2392,18 @@ static void geo_run_views(d3d_meta *m, GeoAsync *g) {      // the views: each be
 }  // namespace d3d
 
 extern "C" {
+
+// (levels of the first chain: 1 = the first strided grid gets a read-back of its own, 0 = one chain for all levels)
+int d3d_grid_chain_head(int levels) {
+  const int was = g_chain_head;
+  g_chain_head = levels < 0 ? 0 : levels;
+  return was;
+}
+int d3d_grid_chain_enable(int on) {
+  const int was = g_chain_enabled ? 1 : 0;
+  g_chain_enabled = on != 0;
+  return was;
+}
 
 int d3d_geometry_async_start(d3d_meta *m, const int *specs, int n, void *stream, void *view_stream) {
   D3D_REQUIRE(m && (n == 0 || specs) && n >= 0 && n <= 128, "geometry_async_start: bad arguments");

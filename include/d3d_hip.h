@@ -54,6 +54,13 @@ int d3d_meta_arena_used(d3d_meta *m, size_t *bytes_host);
  * convolutions of the finer levels run on another one.  The caller orders the two streams with events.  Reset by
  * d3d_meta_clear.                                                                                                    */
 int d3d_meta_set_geometry_stream(d3d_meta *m, void *stream, int enable);
+/* Measurement / A-B switch: the geometry thread builds the strided grids of a d3d_geometry_async_start chain WITHOUT a
+ * read-back between the levels (1, default; grid.hip run_grid_chain) or one d3d_conv_prepare call -- and read-back -- per
+ * level (0).  Same results.  -> the previous setting.  Also settable through the environment: D3D_GRID_CHAIN=0.        */
+int d3d_grid_chain_enable(int on);
+/* ... and how many of the leading levels form a chain (and read-back) of their own before the chain over the rest (default
+ * 1: the first strided grid is wanted long before a chain over all levels ends; 0: one chain).  -> previous setting.   */
+int d3d_grid_chain_head(int levels);
 /* The chain of strided grids run by a thread of the library (no reference counterpart; every new grid costs one blocking
  * read-back of its site count, during which a caller that builds the chain itself cannot enqueue feature kernels).
  * start: `specs` = n x 13 ints (kind, in_size[3], out_size[3], filter[3], stride[3]), built in order:
