@@ -1596,10 +1596,12 @@ int d3d_input_layer_build_prefetch(d3d_meta *m, const int64_t *coords, int n, in
   D3D_HIP_CHECK(fill_ones(tab, sizeof(HashEntry) * g.cap, s));
   int n_active = 0;
   if (n > 0) {
+    // [0] site count, [1..4] extents of the points (k_insert_points).  NOT part of the scratch released below: the
+    // prefetched neighbour probes read the count from it while other streams may already be allocating from this lane.
+    D3D_ALLOC(total, int32_t, A, 8);
     size_t mark = A.used;
     D3D_ALLOC(flag, int32_t, A, n);
     D3D_ALLOC(rank, int32_t, A, n);
-    D3D_ALLOC(total, int32_t, A, 8);            // [0] site count, [1..4] extents of the points (k_insert_points)
     D3D_HIP_CHECK(hipMemsetAsync(total, 0, 8 * sizeof(int32_t), s));
     hipLaunchKernelGGL(k_insert_points, grid1d(n), dim3(256), 0, s, coords, n, ncols, tab, g.cap, pslot, total + 1);
     hipLaunchKernelGGL(k_flag_first, grid1d(n), dim3(256), 0, s, pslot, tab, n, flag);

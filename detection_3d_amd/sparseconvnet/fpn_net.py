@@ -24,6 +24,8 @@ PLAN_LANE = os.environ.get("D3D_PLAN_LANE", "0") != "0"   # ... and each level's
 ASYNC_GEOMETRY = os.environ.get("D3D_ASYNC_GEOMETRY", "1") != "0"   # the grid chain is run by a thread of the library
                     # (d3d_geometry_async_*): its count read-backs no longer stop this thread from enqueueing
 ASYNC_VIEWS = os.environ.get("D3D_ASYNC_VIEWS", "1") != "0"         # ... and that thread also enqueues the views (third stream)
+SIDE_START = os.environ.get("D3D_SIDE_START", "scene")              # "main": side streams wait for the caller's stream at the
+                    # input grid (and the point lists go to the geometry stream), as before the grid chain -- A/B runs
 _GEO_STREAMS = {}   # (device, caller's stream) -> high-priority side streams
 
 
@@ -213,9 +215,12 @@ class FPN_Net(torch.nn.Module):
         def after_input_build(md, size):
             # The host has just seen the input grid's site count, i.e. the grid is complete: the side streams need not
             # wait for the caller's stream, which already holds the hash probes of level 0's rulebook (~0.1 ms).
-            geo.wait_event(scene_start)
+            if SIDE_START == "main":
+                geo.wait_stream(main)
+            else:
+                geo.wait_event(scene_start)
             md.set_geometry_stream(geo.cuda_stream)
-            if plan is not None:
+            if plan is not None and SIDE_START != "main":
                 plan.wait_event(scene_start)
                 with torch.cuda.stream(plan):
                     scn.SCN.InputLayer_prepare(md)          # point lists: own scratch (no lane of the arena), ~0.1 ms
