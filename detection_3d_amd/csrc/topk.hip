@@ -125,10 +125,24 @@ __global__ __launch_bounds__(kTopkThreads) void k_topk_select(TopkArgs a) {
     const uint32_t fixed_mask = level == 0 ? 0u : (0xffffffffu << (shift + nbits[level]));
     for (int i = tid; i < 2048; i += kTopkThreads) hist[i] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += kTopkThreads) {
-      if (!valid(i)) continue;
-      const uint32_t key = f32_ordered(topk_value(a, i, g));
-      if ((key & fixed_mask) == prefix) atomicAdd(&hist[(key >> shift) & (uint32_t)(nb - 1)], 1u);
+    // (scores of one map crowd into few bins -- a random-init head puts every sigmoid next to 0.5 -- and 64 lanes adding to
+    //  one LDS word serialise: the lanes of a wave that share the first active lane's bin add once, together)
+    for (int i0 = 0; i0 < n; i0 += kTopkThreads) {
+      const int i = i0 + tid;
+      bool in = false;
+      uint32_t bin = 0;
+      if (i < n && valid(i)) {
+        const uint32_t key = f32_ordered(topk_value(a, i, g));
+        in = (key & fixed_mask) == prefix;
+        bin = (key >> shift) & (uint32_t)(nb - 1);
+      }
+      unsigned long long todo = __ballot(in);
+      if (todo) {
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, __builtin_ctzll(todo));
+        const unsigned long long same = __ballot(in && bin == b0);
+        if (lane == (int)__builtin_ctzll(same)) atomicAdd(&hist[b0], (uint32_t)__popcll(same));
+        if (in && bin != b0) atomicAdd(&hist[bin], 1u);
+      }
     }
     __syncthreads();
     if (level < 2) find_bin_from_top<2048>(hist, want, wtot, pick);

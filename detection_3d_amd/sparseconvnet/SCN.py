@@ -339,9 +339,10 @@ _TLS = threading.local()
 
 
 def set_after_input_build(hook, prefetch_filter=None):
-    """hook(metadata, spatial_size) is called by this thread's next InputLayer_updateOutput calls between the grid
-    build (whose site count has just been read back) and the feature pass of the input layer -- where a caller can
-    start the level-0 rulebook on another stream (FPN_Net._forward_two_lane).  None removes it.
+    """hook(metadata, spatial_size[, run_forward]) is called by this thread's next InputLayer_updateOutput calls between
+    the grid build (whose site count has just been read back) and the feature pass of the input layer -- where a caller
+    can start the level-0 rulebook on another stream (FPN_Net._forward_two_lane) and, through run_forward(stream), place
+    the feature pass itself.  None removes it.
     prefetch_filter: the filter of the submanifold rulebook the caller will prepare first on the same stream; its
     neighbour table is then probed while the host waits for the site count (d3d_input_layer_build_prefetch)."""
     _TLS.after_input_build = hook
@@ -366,13 +367,30 @@ def InputLayer_updateOutput(m, spatial_size, input_coords, input_features, outpu
                                                int(batch_size), int(mode), ints(pre) if pre is not None else None,
                                                stream_of(), ctypes.byref(na)))
     m._in_active = na.value
+    planes = input_features.shape[1]
+    output_features.resize_(na.value, planes)       # (allocated on the caller's stream, whichever stream fills it)
+    feats = input_features.contiguous()
+    done = []
+
+    def run_forward(on=None):
+        """the input layer's feature pass (d3d_input_layer_forward), on stream `on` (a torch stream) or the current one;
+        the hook may call it where it suits its streams -- e.g. right behind the point lists on a side stream"""
+        if done:
+            return
+        done.append(True)
+        if on is None:
+            check(lib().d3d_input_layer_forward(m._h, ptr(feats), planes, ptr(output_features), stream_of()))
+        else:
+            with torch.cuda.stream(on):
+                check(lib().d3d_input_layer_forward(m._h, ptr(feats), planes, ptr(output_features), stream_of()))
+
     hook = getattr(_TLS, "after_input_build", None)
     if hook is not None:
-        hook(m, spatial_size)
-    planes = input_features.shape[1]
-    output_features.resize_(na.value, planes)
-    feats = input_features.contiguous()
-    check(lib().d3d_input_layer_forward(m._h, ptr(feats), planes, ptr(output_features), stream_of()))
+        if hook.__code__.co_argcount >= 3:
+            hook(m, spatial_size, run_forward)
+        else:
+            hook(m, spatial_size)
+    run_forward()
 
 
 def _bn_struct(bn, stats=None):

@@ -212,7 +212,7 @@ class FPN_Net(torch.nn.Module):
         scene_start = pool[-2]
         scene_start.record(main)
 
-        def after_input_build(md, size):
+        def after_input_build(md, size, run_forward=None):
             # The host has just seen the input grid's site count, i.e. the grid is complete: the side streams need not
             # wait for the caller's stream, which already holds the hash probes of level 0's rulebook (~0.1 ms).
             if SIDE_START == "main":
@@ -224,6 +224,8 @@ class FPN_Net(torch.nn.Module):
                 plan.wait_event(scene_start)
                 with torch.cuda.stream(plan):
                     scn.SCN.InputLayer_prepare(md)          # point lists: own scratch (no lane of the arena), ~0.1 ms
+                    if run_forward is not None:             # ... and the per-voxel means right behind them, beside the
+                        run_forward(plan)                   # sort of level 0's rulebook on the caller's stream
                     plan0.record(plan)
             else:
                 with torch.cuda.stream(geo):
