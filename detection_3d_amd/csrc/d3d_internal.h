@@ -187,6 +187,16 @@ struct d3d_meta {
   uint32_t *pre_mask = nullptr;
   int pre_filt[3] = {0, 0, 0};
   hipStream_t pre_stream = nullptr;
+  // ... and, sized by the point count like the table, the rest of that rulebook (sort by mask, transpose): enqueued
+  // behind the probes before the host has the site count; registered as a plan once the count is back
+  bool pre_plan_built = false;
+  d3d::Plan pre_plan;              // (rows / blocks / gathered rows are filled in when the count is back)
+  void *pre_tab = nullptr;         // the input grid's hash table (known before the grid is registered)
+  // the input layer's point lists, built on a stream of the library's own right behind the grid (no count needed:
+  // everything is sized by the point count); consumers wait for lists_ev
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t grid_ev = nullptr, lists_ev = nullptr;
+  bool lists_on_aux = false;
   hipEvent_t count_ev = nullptr;   // marks the count copy, so that the host does not wait for the prefetch behind it
   size_t arena_cap_full = 0;
   // the three maps above may be read by the caller's thread while the geometry thread (d3d_geometry_async_start) adds
@@ -202,7 +212,8 @@ namespace d3d {
 int scan_exclusive_i32(const int32_t *in, int32_t *out, int n, int32_t *total_dev, Arena &scratch,
                        hipStream_t s);
 int sort_pairs_u32(const uint32_t *keys_in, uint32_t *keys_out, const int32_t *vals_in,
-                   int32_t *vals_out, int n, int bits, Arena &scratch, hipStream_t s, bool descending);
+                   int32_t *vals_out, int n, int bits, Arena &scratch, hipStream_t s, bool descending,
+                   const int32_t *n_dev = nullptr);
 int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan, hipStream_t s,
                   uint32_t *mask_in);
 int plan_rules(d3d_meta *m, Plan &p, hipStream_t s, long *out);

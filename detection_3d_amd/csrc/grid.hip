@@ -131,11 +131,14 @@ __device__ __forceinline__ uint32_t rs_digit(uint32_t k, int shift, bool desc) {
 }
 
 // hist[digit][tile] of one pass
+// n_dev (may be null): the element count on the device, for a sort enqueued with an upper bound `n` (and its n_tiles)
 template <int DB>
 __global__ __launch_bounds__(kRsThreads) void k_rs_count(const uint32_t *__restrict__ keys, int n, int n_tiles, int shift,
-                                                         int desc, uint32_t *__restrict__ hist) {
+                                                         int desc, uint32_t *__restrict__ hist,
+                                                         const int32_t *__restrict__ n_dev) {
   constexpr int BINS = 1 << DB;
   __shared__ uint32_t h[BINS];
+  if (n_dev) n = *n_dev;
   for (int b = threadIdx.x; b < BINS; b += kRsThreads) h[b] = 0;
   __syncthreads();
   const int base = blockIdx.x * kRsTile;
@@ -183,8 +186,10 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const uint32_t *__res
                                                            int shift, int desc, const uint32_t *__restrict__ hist,
                                                            const uint32_t *__restrict__ totals,
                                                            uint32_t *__restrict__ keys_out,
-                                                           int32_t *__restrict__ vals_out) {
+                                                           int32_t *__restrict__ vals_out,
+                                                           const int32_t *__restrict__ n_dev) {
   constexpr int NW = kRsThreads / 64, BINS = 1 << DB, PER = BINS / kRsThreads;
+  if (n_dev) n = *n_dev;
   __shared__ uint32_t wcnt[NW][BINS];
   __shared__ uint32_t wave_tot[NW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -256,11 +261,12 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const uint32_t *__res
 
 template <int DB>
 static void rs_pass(const uint32_t *ksrc, const int32_t *vsrc, int n, int n_tiles, int shift, bool desc, uint32_t *hist,
-                    uint32_t *totals, uint32_t *kdst, int32_t *vdst, hipStream_t s) {
-  hipLaunchKernelGGL(k_rs_count<DB>, dim3(n_tiles), dim3(kRsThreads), 0, s, ksrc, n, n_tiles, shift, desc ? 1 : 0, hist);
+                    uint32_t *totals, uint32_t *kdst, int32_t *vdst, hipStream_t s, const int32_t *n_dev) {
+  hipLaunchKernelGGL(k_rs_count<DB>, dim3(n_tiles), dim3(kRsThreads), 0, s, ksrc, n, n_tiles, shift, desc ? 1 : 0, hist,
+                     n_dev);
   hipLaunchKernelGGL(k_rs_scan, dim3(1 << DB), dim3(kRsThreads), 0, s, hist, n_tiles, totals);
   hipLaunchKernelGGL(k_rs_scatter<DB>, dim3(n_tiles), dim3(kRsThreads), 0, s, ksrc, vsrc, n, n_tiles, shift, desc ? 1 : 0,
-                     hist, totals, kdst, vdst);
+                     hist, totals, kdst, vdst, n_dev);
 }
 static inline void rs_layout(int bits, int &passes, int &db) {
   passes = std::max(1, (bits + 9) / 10);
@@ -276,7 +282,8 @@ size_t sort_scratch_bytes(int n, int bits) {
 // keys_out may be null: the sorted keys are not wanted (saves the last pass's key stores).  `scratch` provides the
 // intermediate buffers and the histograms (released by the caller's mark).
 int sort_pairs_u32(const uint32_t *keys_in, uint32_t *keys_out, const int32_t *vals_in,
-                   int32_t *vals_out, int n, int bits, Arena &scratch, hipStream_t s, bool descending) {
+                   int32_t *vals_out, int n, int bits, Arena &scratch, hipStream_t s, bool descending,
+                   const int32_t *n_dev) {
   if (n <= 0) return D3D_OK;
   int passes, db;
   rs_layout(bits, passes, db);
@@ -297,9 +304,9 @@ int sort_pairs_u32(const uint32_t *keys_in, uint32_t *keys_out, const int32_t *v
     const bool last = p == passes - 1;
     uint32_t *kdst = last ? keys_out : ktmp[p & 1];
     int32_t *vdst = last ? vals_out : vtmp[p & 1];
-    if (db == 8) rs_pass<8>(ksrc, vsrc, n, n_tiles, db * p, descending, hist, totals, kdst, vdst, s);
-    else if (db == 9) rs_pass<9>(ksrc, vsrc, n, n_tiles, db * p, descending, hist, totals, kdst, vdst, s);
-    else rs_pass<10>(ksrc, vsrc, n, n_tiles, db * p, descending, hist, totals, kdst, vdst, s);
+    if (db == 8) rs_pass<8>(ksrc, vsrc, n, n_tiles, db * p, descending, hist, totals, kdst, vdst, s, n_dev);
+    else if (db == 9) rs_pass<9>(ksrc, vsrc, n, n_tiles, db * p, descending, hist, totals, kdst, vdst, s, n_dev);
+    else rs_pass<10>(ksrc, vsrc, n, n_tiles, db * p, descending, hist, totals, kdst, vdst, s, n_dev);
     ksrc = kdst;
     vsrc = vdst;
   }
@@ -836,14 +843,21 @@ __global__ __launch_bounds__(256) void k_count_rules(const int32_t *__restrict__
 // per-block offset masks (ballot over the 32 positions of a block), so that the plan needs one launch
 // after the sort.  HBM-bound: 2 * npos * K * 4 bytes.
 static constexpr int kTP = 128;
+// n_dev (may be null): the row count on the device; the launch is then sized by an upper bound and the layout (row
+// stride npos of nbrT) is derived from the true count, exactly as a launch that knew it would have laid it out
 __global__ __launch_bounds__(256) void k_plan_finish(const int32_t *__restrict__ nbr, int32_t *__restrict__ rows,
                                                      int n_rows, int npos, int K, int32_t *__restrict__ nbrT,
-                                                     uint32_t *__restrict__ blkmask) {
+                                                     uint32_t *__restrict__ blkmask, const int32_t *__restrict__ n_dev) {
   extern __shared__ int32_t tile[];  // [kTP][S], S odd
   __shared__ int32_t rloc[kTP];
   __shared__ uint32_t bm[kTP / 32];
   const int S = K | 1;
   const int p0 = blockIdx.x * kTP;
+  if (n_dev) {
+    n_rows = *n_dev;
+    npos = ((n_rows + 31) / 32) * 32;
+    if (p0 >= npos) return;
+  }
   const int np = min(kTP, npos - p0);  // multiple of 32
   if (threadIdx.x < kTP) {
     const int p = p0 + threadIdx.x;
@@ -970,7 +984,7 @@ int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan
   if (n_rows <= kSmallMax) {
     hipLaunchKernelGGL(k_plan_small, dim3(1), dim3(kSmallThreads), 0, s, nbr, mask_in, n_rows, K, rows);
     hipLaunchKernelGGL(k_plan_finish, dim3((npos + kTP - 1) / kTP), dim3(256), (size_t)kTP * (K | 1) * sizeof(int32_t),
-                       s, nbr, rows, n_rows, npos, K, nbrT, blkmask);
+                       s, nbr, rows, n_rows, npos, K, nbrT, blkmask, (const int32_t *)nullptr);
     D3D_LAUNCH_CHECK();
     return D3D_OK;
   }
@@ -991,10 +1005,10 @@ int finalize_plan(d3d_meta *m, const int32_t *nbr, int n_rows, int K, Plan &plan
   // k = s = 2 plans unsorted (absent gathers cost no memory traffic) saves four sorts per building and costs the
   // strided convolutions 0.25 ms of zero tiles: 6.45 against 6.37 ms per building.
   D3D_REQUIRE(m->iota && n_rows <= m->iota_n, "finalize_plan: %d rows exceed the input layer's %d points", n_rows, m->iota_n);
-  int rc = sort_pairs_u32(mask, nullptr, m->iota, rows, n_rows, std::min(K, 32), A, s, true);   // low K bits: the mask
+  int rc = sort_pairs_u32(mask, nullptr, m->iota, rows, n_rows, std::min(K, 32), A, s, true, nullptr);   // low K bits: the mask
   if (rc) return rc;
   hipLaunchKernelGGL(k_plan_finish, dim3((npos + kTP - 1) / kTP), dim3(256), (size_t)kTP * (K | 1) * sizeof(int32_t),
-                     s, nbr, rows, n_rows, npos, K, nbrT, blkmask);
+                     s, nbr, rows, n_rows, npos, K, nbrT, blkmask, (const int32_t *)nullptr);
   D3D_LAUNCH_CHECK();
   A.used = mark;  // scratch released (stream-ordered reuse)
   return D3D_OK;
@@ -1411,6 +1425,9 @@ int d3d_meta_destroy(d3d_meta *m) {
   if (m->host_counts) (void)hipHostFree(m->host_counts);
   if (m->count_ev) (void)hipEventDestroy(m->count_ev);
   if (m->chain_ev) (void)hipEventDestroy(m->chain_ev);
+  if (m->grid_ev) (void)hipEventDestroy(m->grid_ev);
+  if (m->lists_ev) (void)hipEventDestroy(m->lists_ev);
+  if (m->aux_stream) (void)hipStreamDestroy(m->aux_stream);
   delete m;
   return D3D_OK;
 }
@@ -1422,6 +1439,9 @@ int d3d_meta_clear(d3d_meta *m) {
   m->arena.cap = m->arena_cap_full;
   m->pre_nbr = nullptr;
   m->pre_mask = nullptr;
+  m->pre_plan_built = false;
+  m->pre_tab = nullptr;
+  m->lists_on_aux = false;
   m->feat_arena.used = 0;
   m->feat_arena.cap = m->feat_cap_full;
   m->plan_arena = Arena();
@@ -1538,6 +1558,9 @@ int d3d_voxelize(const float *pcl, int n, int nfeat, double scale, const int *fu
   return D3D_OK;
 }
 
+namespace d3d {
+static int build_point_lists(d3d_meta *m, hipStream_t s, bool by_bound);
+}
 static size_t point_list_scratch_bytes(int n) {   // what ensure_point_lists carves: site of every point, counts, scan sums, sort
   const size_t nn = (size_t)std::max(n, 1);
   return nn * 4 + 256 + (nn + 2) * 4 + 256 + ((nn + 1 + kScanTile - 1) / kScanTile) * 4 + 256 + sort_scratch_bytes(n, 32) + 4096;
@@ -1599,6 +1622,16 @@ int d3d_input_layer_build_prefetch(d3d_meta *m, const int64_t *coords, int n, in
     // [0] site count, [1..4] extents of the points (k_insert_points).  NOT part of the scratch released below: the
     // prefetched neighbour probes read the count from it while other streams may already be allocating from this lane.
     D3D_ALLOC(total, int32_t, A, 8);
+    // (the arrays of the rulebook that is enqueued below before the count is back: sized by the point count)
+    const int pre_K = prefetch_filter ? prefetch_filter[0] * prefetch_filter[1] * prefetch_filter[2] : 0;
+    const int nblk_b = (n + 31) / 32, npos_b = nblk_b * 32;
+    int32_t *prows = nullptr, *pnbrT = nullptr;
+    uint32_t *pblk = nullptr;
+    if (pre_K > 1 && pre_K <= 32) {
+      prows = A.get<int32_t>((size_t)npos_b + 1);
+      pnbrT = A.get<int32_t>((size_t)npos_b * pre_K + 1);
+      pblk = A.get<uint32_t>((size_t)nblk_b + 1);
+    }
     size_t mark = A.used;
     D3D_ALLOC(flag, int32_t, A, n);
     D3D_ALLOC(rank, int32_t, A, n);
@@ -1612,23 +1645,56 @@ int d3d_input_layer_build_prefetch(d3d_meta *m, const int64_t *coords, int n, in
     D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[0], total, 5 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     bool prefetched = false;
     if (prefetch_filter) {
-      // The neighbour table of the submanifold rulebook the caller will ask for first (hash probes of every site,
-      // the longest kernel of a rulebook) starts now, sized by the point count and reading the site count on the
-      // device, so that it runs while the host waits for the count and walks back up to d3d_subm_prepare.  It lives at
-      // the top of the geometry lane, which stays that much shorter for the scene.
+      // Everything of the pass's start that does not need the site count ON THE HOST is enqueued now, sized by the point
+      // count and reading the site count on the device, so that the GPU keeps working while the count travels back:
+      //  * on a stream of the library's own, right behind the grid: the input layer's point lists (counters, scan and
+      //    sort cover n sites' worth of entries; sites past the true count hold no points);
+      //  * on this stream: the submanifold rulebook the caller will ask for first -- hash probes of every site, the sort
+      //    of the rows by offset mask, the transposed table.  Raw table, masks and sort scratch live at the top of the
+      //    geometry lane, which stays that much shorter for the scene.
+      if (m->pl_scratch) {
+        if (!m->aux_stream) {
+          D3D_HIP_CHECK(hipStreamCreateWithFlags(&m->aux_stream, hipStreamNonBlocking));
+          D3D_HIP_CHECK(hipEventCreateWithFlags(&m->grid_ev, hipEventDisableTiming));
+          D3D_HIP_CHECK(hipEventCreateWithFlags(&m->lists_ev, hipEventDisableTiming));
+        }
+        D3D_HIP_CHECK(hipEventRecord(m->grid_ev, s));
+        D3D_HIP_CHECK(hipStreamWaitEvent(m->aux_stream, m->grid_ev, 0));
+        m->pre_tab = tab;
+        if (int rc2 = build_point_lists(m, m->aux_stream, true)) return rc2;
+        D3D_HIP_CHECK(hipEventRecord(m->lists_ev, m->aux_stream));
+        m->in_lists = true;
+        m->lists_on_aux = true;
+      }
       const int K = prefetch_filter[0] * prefetch_filter[1] * prefetch_filter[2];
       const size_t raw = (((size_t)n * K + 1) * sizeof(int32_t) + 255) & ~size_t(255);
       const size_t msk = ((size_t)n * sizeof(uint32_t) + 511) & ~size_t(255);
-      if (K > 1 && K <= 32 && A.used + raw + msk + (64u << 20) < A.cap) {
-        A.cap = (A.cap - raw - msk) & ~size_t(255);
-        m->pre_mask = (uint32_t *)(A.base + A.cap);
-        m->pre_nbr = (int32_t *)(A.base + A.cap + msk);
+      const size_t srt = (sort_scratch_bytes(n, std::min(K, 32)) + 255) & ~size_t(255);
+      if (K > 1 && K <= 32 && prows && pnbrT && pblk && A.used + raw + msk + srt + (64u << 20) < A.cap) {
+        A.cap = (A.cap - raw - msk - srt) & ~size_t(255);
+        Arena sc;
+        sc.base = A.base + A.cap;
+        sc.cap = srt;
+        m->pre_mask = (uint32_t *)(A.base + A.cap + srt);
+        m->pre_nbr = (int32_t *)(A.base + A.cap + srt + msk);
         for (int d = 0; d < 3; d++) m->pre_filt[d] = prefetch_filter[d];
         m->pre_stream = s;
         if (!m->count_ev) D3D_HIP_CHECK(hipEventCreateWithFlags(&m->count_ev, hipEventDisableTiming));
-        D3D_HIP_CHECK(hipEventRecord(m->count_ev, s));          // the host waits for the count, not for the table
+        D3D_HIP_CHECK(hipEventRecord(m->count_ev, s));          // the host waits for the count, not for what follows
         if (int rc2 = launch_subm_nbr(loc, n, prefetch_filter, tab, g.cap, m->pre_nbr, m->pre_mask, total, s)) return rc2;
         prefetched = true;
+        // rows sorted by offset mask (low K bits of the keys the probes left), then the transposed table
+        Plan &p = m->pre_plan;
+        p = Plan();
+        p.K = K;
+        p.rows = prows;
+        p.nbrT = pnbrT;
+        p.blkmask = pblk;
+        if (int rc2 = sort_pairs_u32(m->pre_mask, nullptr, m->iota, p.rows, n, std::min(K, 32), sc, s, true, total)) return rc2;
+        hipLaunchKernelGGL(k_plan_finish, dim3((npos_b + kTP - 1) / kTP), dim3(256), (size_t)kTP * (K | 1) * sizeof(int32_t), s,
+                           m->pre_nbr, p.rows, n, npos_b, K, p.nbrT, p.blkmask, (const int32_t *)total);
+        D3D_LAUNCH_CHECK();
+        m->pre_plan_built = true;
       }
     }
     if (prefetched) D3D_HIP_CHECK(hipEventSynchronize(m->count_ev));
@@ -1643,6 +1709,13 @@ int d3d_input_layer_build_prefetch(d3d_meta *m, const int64_t *coords, int n, in
   {
     D3D_LOCK(m);
     m->grids[Size3{size[0], size[1], size[2]}] = g;
+    if (m->pre_plan_built) {        // the rulebook enqueued above, now that its row count is known on the host
+      Plan &p = m->pre_plan;
+      p.n_rows = p.n_in = n_active;
+      p.n_blk = (n_active + 31) / 32;
+      p.n_rules = n_active == 0 ? 0 : -1;
+      m->plans.emplace(make_key(0, size, m->pre_filt, nullptr), p);
+    }
   }
   *n_active_host = n_active;
   return D3D_OK;
@@ -1654,14 +1727,19 @@ namespace d3d {
 // Per-site point lists in input order (stable sort of point ids by site id), built by the first consumer on ITS
 // stream with temporaries from that stream's lane of the arena: the grid exists as soon as d3d_input_layer_build
 // returns, so a caller may start the level-0 rulebook on another stream while the lists are sorted here.
-int ensure_point_lists(d3d_meta *m, hipStream_t s) {
-  if (m->in_lists || m->in_n == 0) return D3D_OK;
-  const int n = m->in_n, n_active = m->in_active;
+// by_bound: nothing in the build depends on the site count (counters, scan and sort cover all n points' worth of
+// sites: the sites past the true count hold zero points), so the lists can be enqueued before the count is read back.
+static int build_point_lists(d3d_meta *m, hipStream_t s, bool by_bound) {
+  const int n = m->in_n, n_sites = by_bound ? m->in_n : m->in_active;
   std::map<Size3, Grid>::iterator it;
-  {
+  HashEntry *tab = nullptr;
+  if (by_bound) {
+    tab = (HashEntry *)m->pre_tab;
+  } else {
     D3D_LOCK(m);
     it = m->grids.find(m->in_size);
     D3D_REQUIRE(it != m->grids.end(), "input layer: grid not found");
+    tab = it->second.tab;
   }
   Arena own;                      // the region the build set aside: independent of the stream's lane
   own.base = m->pl_scratch;
@@ -1671,16 +1749,27 @@ int ensure_point_lists(d3d_meta *m, hipStream_t s) {
   D3D_ALLOC(psite, uint32_t, A, n);
   D3D_ALLOC(cnt, int32_t, A, (size_t)n + 1);
   D3D_REQUIRE(m->iota && n <= m->iota_n, "input layer: point index table missing");
-  D3D_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int32_t) * ((size_t)n_active + 1), s));
-  hipLaunchKernelGGL(k_point_site, grid1d(n), dim3(256), 0, s, m->in_pslot, it->second.tab, n, psite, cnt);
-  int rc = scan_exclusive_i32(cnt, m->in_off, n_active + 1, nullptr, A, s);
+  D3D_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int32_t) * ((size_t)n_sites + 1), s));
+  hipLaunchKernelGGL(k_point_site, grid1d(n), dim3(256), 0, s, m->in_pslot, tab, n, psite, cnt);
+  int rc = scan_exclusive_i32(cnt, m->in_off, n_sites + 1, nullptr, A, s);
   if (rc) return rc;
   int bits = 1;
-  while ((1L << bits) < n_active) bits++;
+  while ((1L << bits) < n_sites) bits++;
   rc = sort_pairs_u32(psite, nullptr, m->iota, m->in_idx, n, bits, A, s, false);
   if (rc) return rc;
   D3D_LAUNCH_CHECK();
   A.used = mark;
+  return D3D_OK;
+}
+int ensure_point_lists(d3d_meta *m, hipStream_t s) {
+  if (m->in_n == 0) return D3D_OK;
+  if (m->in_lists) {
+    // built on the library's own stream by the input-layer build: this stream waits for them
+    if (m->lists_on_aux) D3D_HIP_CHECK(hipStreamWaitEvent(s, m->lists_ev, 0));
+    return D3D_OK;
+  }
+  int rc = build_point_lists(m, s, false);
+  if (rc) return rc;
   m->in_lists = true;
   return D3D_OK;
 }

@@ -234,8 +234,11 @@ class FPN_Net(torch.nn.Module):
             # level 0's 3x3x3 rulebook on this stream (sort + transpose of the probed table, ~0.15 ms); the plan lane is
             # carved out of the feature lane only afterwards, and its stream continues behind this build (whose scratch
             # may reach into what becomes the plan lane)
+            _tmark("input grid known (host)", -1, host=True)
             scn.SCN.SubmanifoldConvolution_prepare(size, (3,) * self.dimension, md)
+            _tmark("level-0 rulebook", -1, main)
             if plan is not None:
+                _tmark("point lists + input means", -1, plan)
                 plan.wait_stream(main)
                 md.set_plan_stream(plan.cuda_stream)
             cache = getattr(self, "_spec_cache", None)

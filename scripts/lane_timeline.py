@@ -37,7 +37,7 @@ with torch.no_grad():
         marks, timeline.MARKS = timeline.MARKS, None
         for label, k, ev, host in marks:
             t = (host - h0) * 1e3 if ev is None else start.elapsed_time(ev)
-            rows.setdefault((k, label), []).append(t)
+            rows.setdefault((k, label + (" (host clock)" if ev is None and k < 0 else "")), []).append(t)
             if ev is not None and k < 0:
                 rows.setdefault((k, label + " [host enqueued]"), []).append((host - h0) * 1e3)
         rows.setdefault((-1, "pass done"), []).append(start.elapsed_time(end))
