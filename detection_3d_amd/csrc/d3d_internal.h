@@ -79,6 +79,7 @@ struct Grid {
   HashEntry *tab = nullptr;
   int32_t *loc = nullptr;  // [n,4] x,y,z,b
   int32_t *extent = nullptr;  // device int[3]: 1 + max coordinate per axis (filled on first use, grid_extent)
+  int32_t *dense = nullptr;    // 1 + site id per cell of the box [hext[3]][hext[0]][hext[1]][hext[2]], 0 = empty (grid_dense_index)
   int hext[4] = {0, 0, 0, 0};  // host-side UPPER BOUNDS of 1 + max x, y, z, example index (0: unknown); bound the site counts
                                // of the grids built from this one (grid chain)
 };
@@ -195,7 +196,7 @@ struct d3d_meta {
   // the input layer's point lists, built on a stream of the library's own right behind the grid (no count needed:
   // everything is sized by the point count); consumers wait for lists_ev
   hipStream_t aux_stream = nullptr;
-  hipEvent_t grid_ev = nullptr, lists_ev = nullptr;
+  hipEvent_t grid_ev = nullptr, lists_ev = nullptr, fill_ev = nullptr;
   bool lists_on_aux = false;
   hipEvent_t count_ev = nullptr;   // marks the count copy, so that the host does not wait for the prefetch behind it
   size_t arena_cap_full = 0;
@@ -221,7 +222,7 @@ const Plan *find_plan(d3d_meta *m, int kind, const int *in_size, const int *filt
 int get_deconv_plan(d3d_meta *m, const int *fine_size, const int *filt, const int *stride,
                     hipStream_t s, const Plan **out);
 
-int grid_extent(d3d_meta *m, Grid &g, hipStream_t s);  // grid.hip: ensures g.extent
+int grid_extent(d3d_meta *m, Grid &g, hipStream_t s);  // grid.hip: ensures g.extent (and, for small boxes, g.dense)
 int check_build_stream(d3d_meta *m, hipStream_t s, const char *what);
 int ensure_point_lists(d3d_meta *m, hipStream_t s);
 Arena &lane_arena(d3d_meta *m, hipStream_t s);

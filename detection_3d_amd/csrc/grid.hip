@@ -798,13 +798,24 @@ __global__ __launch_bounds__(256) void k_subm_nbr_sym(const int32_t *__restrict_
 // The half-probe form pays two fills: measured rulebook builds 0.285 -> 0.230 ms at 462 k sites, 0.245 -> 0.208 at 371 k,
 // 0.113 -> 0.130 at 193 k, 0.084 -> 0.104 at 57 k.
 static constexpr int kSymMinSites = 262144;
+static bool subm_nbr_is_sym(int n_bound, const int *filt) {
+  const int K = filt[0] * filt[1] * filt[2];
+  return (filt[0] & 1) && (filt[1] & 1) && (filt[2] & 1) && K > 1 && n_bound >= kSymMinSites;
+}
+// the two fills the half-probe form needs (table -1, masks 0); a caller may run them ahead of time on another stream
+static int subm_nbr_prefill(int n_bound, const int *filt, int32_t *nbr, uint32_t *mask, hipStream_t s) {
+  const int K = filt[0] * filt[1] * filt[2];
+  D3D_HIP_CHECK(fill_ones(nbr, sizeof(int32_t) * ((size_t)n_bound * K + 1), s));
+  D3D_HIP_CHECK(hipMemsetAsync(mask, 0, sizeof(uint32_t) * (size_t)n_bound, s));
+  return D3D_OK;
+}
 static int launch_subm_nbr(const int32_t *loc, int n_bound, const int *filt, const HashEntry *tab, int cap, int32_t *nbr,
-                           uint32_t *mask, const int32_t *n_dev, hipStream_t s) {
+                           uint32_t *mask, const int32_t *n_dev, hipStream_t s, bool prefilled = false) {
   if (n_bound <= 0) return D3D_OK;
   const int K = filt[0] * filt[1] * filt[2];
-  if ((filt[0] & 1) && (filt[1] & 1) && (filt[2] & 1) && K > 1 && n_bound >= kSymMinSites) {
-    D3D_HIP_CHECK(fill_ones(nbr, sizeof(int32_t) * ((size_t)n_bound * K + 1), s));
-    D3D_HIP_CHECK(hipMemsetAsync(mask, 0, sizeof(uint32_t) * (size_t)n_bound, s));
+  if (subm_nbr_is_sym(n_bound, filt)) {
+    if (!prefilled)
+      if (int rc = subm_nbr_prefill(n_bound, filt, nbr, mask, s)) return rc;
     hipLaunchKernelGGL(k_subm_nbr_sym, grid1d(n_bound, kNbrSites), dim3(256), 0, s, loc, n_bound, filt[0], filt[1], filt[2],
                        tab, cap, nbr, mask, n_dev);
   } else {
@@ -1113,14 +1124,22 @@ int get_deconv_plan(d3d_meta *m, const int *fine_size, const int *filt, const in
   return D3D_OK;
 }
 
-// occupied extent of a grid (1 + max coordinate per axis), what sparse_3d_to_dense_2d crops the dense map to
-__global__ void k_grid_extent(const int32_t *__restrict__ loc, int n, int32_t *__restrict__ extent) {
+// occupied extent of a grid (1 + max coordinate per axis), what sparse_3d_to_dense_2d crops the dense map to; and, when
+// the grid's bounding box is small (host-side bounds `hext` from the input layer / the grid chain), a DENSE INDEX of that
+// box: dense[((b * e0 + x) * e1 + y) * e2 + z] = 1 + site id, 0 = empty.  The rotated RoIAlign samples through it with
+// one load per trilinear corner instead of a probe sequence through the hash table (a pyramid level the pooler reads is
+// ~40 k cells: the index stays in L2 / L1).
+static constexpr long kDenseMaxCells = 8L << 20;
+__global__ void k_grid_extent(const int32_t *__restrict__ loc, int n, int32_t *__restrict__ extent,
+                              int32_t *__restrict__ dense, int e0, int e1, int e2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   int v[3] = {0, 0, 0};
   if (i < n) {
-    v[0] = loc[(size_t)i * 4] + 1;
-    v[1] = loc[(size_t)i * 4 + 1] + 1;
-    v[2] = loc[(size_t)i * 4 + 2] + 1;
+    const int x = loc[(size_t)i * 4], y = loc[(size_t)i * 4 + 1], z = loc[(size_t)i * 4 + 2], b = loc[(size_t)i * 4 + 3];
+    v[0] = x + 1;
+    v[1] = y + 1;
+    v[2] = z + 1;
+    if (dense) dense[(((size_t)b * e0 + x) * e1 + y) * e2 + z] = i + 1;
   }
 #pragma unroll
   for (int d = 0; d < 3; d++) {
@@ -1132,11 +1151,20 @@ __global__ void k_grid_extent(const int32_t *__restrict__ loc, int n, int32_t *_
 }
 int grid_extent(d3d_meta *m, Grid &g, hipStream_t s) {
   if (g.extent) return D3D_OK;
-  D3D_ALLOC(e, int32_t, lane_arena(m, s), 4);
-  D3D_HIP_CHECK(hipMemsetAsync(e, 0, 4 * sizeof(int32_t), s));
-  if (g.n > 0) hipLaunchKernelGGL(k_grid_extent, grid1d(g.n), dim3(256), 0, s, g.loc, g.n, e);
+  Arena &A = lane_arena(m, s);
+  long cells = 0;
+  if (g.hext[0] > 0 && g.hext[3] > 0) {
+    cells = (long)g.hext[3] * g.hext[0] * g.hext[1] * g.hext[2];
+    if (cells > kDenseMaxCells) cells = 0;
+  }
+  D3D_ALLOC(e, int32_t, A, 64 + (size_t)cells);      // [0..3] extent, [64..] dense index: one zero fill for both
+  D3D_HIP_CHECK(hipMemsetAsync(e, 0, (64 + (size_t)cells) * sizeof(int32_t), s));
+  int32_t *dense = cells ? e + 64 : nullptr;
+  if (g.n > 0)
+    hipLaunchKernelGGL(k_grid_extent, grid1d(g.n), dim3(256), 0, s, g.loc, g.n, e, dense, g.hext[0], g.hext[1], g.hext[2]);
   D3D_LAUNCH_CHECK();
   g.extent = e;
+  g.dense = dense;
   return D3D_OK;
 }
 
@@ -1427,6 +1455,7 @@ int d3d_meta_destroy(d3d_meta *m) {
   if (m->chain_ev) (void)hipEventDestroy(m->chain_ev);
   if (m->grid_ev) (void)hipEventDestroy(m->grid_ev);
   if (m->lists_ev) (void)hipEventDestroy(m->lists_ev);
+  if (m->fill_ev) (void)hipEventDestroy(m->fill_ev);
   if (m->aux_stream) (void)hipStreamDestroy(m->aux_stream);
   delete m;
   return D3D_OK;
@@ -1616,7 +1645,6 @@ int d3d_input_layer_build_prefetch(d3d_meta *m, const int64_t *coords, int n, in
   m->in_mode = mode;
   m->in_off = in_off;
   m->in_idx = in_idx;
-  D3D_HIP_CHECK(fill_ones(tab, sizeof(HashEntry) * g.cap, s));
   int n_active = 0;
   if (n > 0) {
     // [0] site count, [1..4] extents of the points (k_insert_points).  NOT part of the scratch released below: the
@@ -1635,6 +1663,47 @@ int d3d_input_layer_build_prefetch(d3d_meta *m, const int64_t *coords, int n, in
     size_t mark = A.used;
     D3D_ALLOC(flag, int32_t, A, n);
     D3D_ALLOC(rank, int32_t, A, n);
+    // Everything of the pass's start that does not need the site count ON THE HOST is enqueued before the count is read
+    // back, sized by the point count and reading the site count on the device, so that the GPU keeps working while the
+    // count travels: on this stream the submanifold rulebook the caller will ask for first -- hash probes of every site,
+    // the sort of the rows by offset mask, the transposed table (raw table, masks and sort scratch live at the top of
+    // the geometry lane, which stays that much shorter for the scene) -- and, on a stream of the library's own, the
+    // fills of that table (beside the point insertion) and the input layer's point lists (beside the probes; counters,
+    // scan and sort cover n sites' worth of entries, sites past the true count hold no points).  Launch ORDER follows
+    // the critical path: the host needs ~4 us per launch, and the probes must not queue behind the lists' 12 launches.
+    bool pre = false, sym = false;
+    size_t raw = 0, msk = 0, srt = 0;
+    if (prefetch_filter && m->pl_scratch) {
+      raw = (((size_t)n * pre_K + 1) * sizeof(int32_t) + 255) & ~size_t(255);
+      msk = ((size_t)n * sizeof(uint32_t) + 511) & ~size_t(255);
+      srt = (sort_scratch_bytes(n, std::min(pre_K, 32)) + 255) & ~size_t(255);
+      pre = pre_K > 1 && pre_K <= 32 && prows && pnbrT && pblk && A.used + raw + msk + srt + (64u << 20) < A.cap;
+    }
+    Arena sc;
+    if (pre) {
+      if (!m->aux_stream) {
+        D3D_HIP_CHECK(hipStreamCreateWithFlags(&m->aux_stream, hipStreamNonBlocking));
+        D3D_HIP_CHECK(hipEventCreateWithFlags(&m->grid_ev, hipEventDisableTiming));
+        D3D_HIP_CHECK(hipEventCreateWithFlags(&m->lists_ev, hipEventDisableTiming));
+        D3D_HIP_CHECK(hipEventCreateWithFlags(&m->fill_ev, hipEventDisableTiming));
+      }
+      A.cap = (A.cap - raw - msk - srt) & ~size_t(255);
+      sc.base = A.base + A.cap;
+      sc.cap = srt;
+      m->pre_mask = (uint32_t *)(A.base + A.cap + srt);
+      m->pre_nbr = (int32_t *)(A.base + A.cap + srt + msk);
+      for (int d = 0; d < 3; d++) m->pre_filt[d] = prefetch_filter[d];
+      m->pre_stream = s;
+      sym = subm_nbr_is_sym(n, prefetch_filter);
+      // the library's stream joins the caller's here (arena reuse from scene to scene is ordered by the caller's stream)
+      D3D_HIP_CHECK(hipEventRecord(m->grid_ev, s));
+      D3D_HIP_CHECK(hipStreamWaitEvent(m->aux_stream, m->grid_ev, 0));
+      if (sym) {
+        if (int rc2 = subm_nbr_prefill(n, prefetch_filter, m->pre_nbr, m->pre_mask, m->aux_stream)) return rc2;
+        D3D_HIP_CHECK(hipEventRecord(m->fill_ev, m->aux_stream));
+      }
+    }
+    D3D_HIP_CHECK(fill_ones(tab, sizeof(HashEntry) * g.cap, s));
     D3D_HIP_CHECK(hipMemsetAsync(total, 0, 8 * sizeof(int32_t), s));
     hipLaunchKernelGGL(k_insert_points, grid1d(n), dim3(256), 0, s, coords, n, ncols, tab, g.cap, pslot, total + 1);
     hipLaunchKernelGGL(k_flag_first, grid1d(n), dim3(256), 0, s, pslot, tab, n, flag);
@@ -1644,64 +1713,40 @@ int d3d_input_layer_build_prefetch(d3d_meta *m, const int64_t *coords, int n, in
     D3D_LAUNCH_CHECK();
     D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[0], total, 5 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     bool prefetched = false;
-    if (prefetch_filter) {
-      // Everything of the pass's start that does not need the site count ON THE HOST is enqueued now, sized by the point
-      // count and reading the site count on the device, so that the GPU keeps working while the count travels back:
-      //  * on a stream of the library's own, right behind the grid: the input layer's point lists (counters, scan and
-      //    sort cover n sites' worth of entries; sites past the true count hold no points);
-      //  * on this stream: the submanifold rulebook the caller will ask for first -- hash probes of every site, the sort
-      //    of the rows by offset mask, the transposed table.  Raw table, masks and sort scratch live at the top of the
-      //    geometry lane, which stays that much shorter for the scene.
-      if (m->pl_scratch) {
-        if (!m->aux_stream) {
-          D3D_HIP_CHECK(hipStreamCreateWithFlags(&m->aux_stream, hipStreamNonBlocking));
-          D3D_HIP_CHECK(hipEventCreateWithFlags(&m->grid_ev, hipEventDisableTiming));
-          D3D_HIP_CHECK(hipEventCreateWithFlags(&m->lists_ev, hipEventDisableTiming));
-        }
-        D3D_HIP_CHECK(hipEventRecord(m->grid_ev, s));
-        D3D_HIP_CHECK(hipStreamWaitEvent(m->aux_stream, m->grid_ev, 0));
-        m->pre_tab = tab;
-        if (int rc2 = build_point_lists(m, m->aux_stream, true)) return rc2;
-        D3D_HIP_CHECK(hipEventRecord(m->lists_ev, m->aux_stream));
-        m->in_lists = true;
-        m->lists_on_aux = true;
-      }
-      const int K = prefetch_filter[0] * prefetch_filter[1] * prefetch_filter[2];
-      const size_t raw = (((size_t)n * K + 1) * sizeof(int32_t) + 255) & ~size_t(255);
-      const size_t msk = ((size_t)n * sizeof(uint32_t) + 511) & ~size_t(255);
-      const size_t srt = (sort_scratch_bytes(n, std::min(K, 32)) + 255) & ~size_t(255);
-      if (K > 1 && K <= 32 && prows && pnbrT && pblk && A.used + raw + msk + srt + (64u << 20) < A.cap) {
-        A.cap = (A.cap - raw - msk - srt) & ~size_t(255);
-        Arena sc;
-        sc.base = A.base + A.cap;
-        sc.cap = srt;
-        m->pre_mask = (uint32_t *)(A.base + A.cap + srt);
-        m->pre_nbr = (int32_t *)(A.base + A.cap + srt + msk);
-        for (int d = 0; d < 3; d++) m->pre_filt[d] = prefetch_filter[d];
-        m->pre_stream = s;
-        if (!m->count_ev) D3D_HIP_CHECK(hipEventCreateWithFlags(&m->count_ev, hipEventDisableTiming));
-        D3D_HIP_CHECK(hipEventRecord(m->count_ev, s));          // the host waits for the count, not for what follows
-        if (int rc2 = launch_subm_nbr(loc, n, prefetch_filter, tab, g.cap, m->pre_nbr, m->pre_mask, total, s)) return rc2;
-        prefetched = true;
-        // rows sorted by offset mask (low K bits of the keys the probes left), then the transposed table
-        Plan &p = m->pre_plan;
-        p = Plan();
-        p.K = K;
-        p.rows = prows;
-        p.nbrT = pnbrT;
-        p.blkmask = pblk;
-        if (int rc2 = sort_pairs_u32(m->pre_mask, nullptr, m->iota, p.rows, n, std::min(K, 32), sc, s, true, total)) return rc2;
-        hipLaunchKernelGGL(k_plan_finish, dim3((npos_b + kTP - 1) / kTP), dim3(256), (size_t)kTP * (K | 1) * sizeof(int32_t), s,
-                           m->pre_nbr, p.rows, n, npos_b, K, p.nbrT, p.blkmask, (const int32_t *)total);
-        D3D_LAUNCH_CHECK();
-        m->pre_plan_built = true;
-      }
+    if (pre) {
+      if (!m->count_ev) D3D_HIP_CHECK(hipEventCreateWithFlags(&m->count_ev, hipEventDisableTiming));
+      D3D_HIP_CHECK(hipEventRecord(m->count_ev, s));          // the host waits for the count, not for what follows
+      // 1. the probes (the longest kernel of the start) ...
+      if (sym) D3D_HIP_CHECK(hipStreamWaitEvent(s, m->fill_ev, 0));
+      if (int rc2 = launch_subm_nbr(loc, n, prefetch_filter, tab, g.cap, m->pre_nbr, m->pre_mask, total, s, sym)) return rc2;
+      prefetched = true;
+      // 2. ... beside them the point lists, behind the grid (count_ev marks it) ...
+      D3D_HIP_CHECK(hipStreamWaitEvent(m->aux_stream, m->count_ev, 0));
+      m->pre_tab = tab;
+      if (int rc2 = build_point_lists(m, m->aux_stream, true)) return rc2;
+      D3D_HIP_CHECK(hipEventRecord(m->lists_ev, m->aux_stream));
+      m->in_lists = true;
+      m->lists_on_aux = true;
+      // 3. ... then the rows sorted by offset mask (low K bits of the keys the probes left) and the transposed table
+      Plan &p = m->pre_plan;
+      p = Plan();
+      p.K = pre_K;
+      p.rows = prows;
+      p.nbrT = pnbrT;
+      p.blkmask = pblk;
+      if (int rc2 = sort_pairs_u32(m->pre_mask, nullptr, m->iota, p.rows, n, std::min(pre_K, 32), sc, s, true, total)) return rc2;
+      hipLaunchKernelGGL(k_plan_finish, dim3((npos_b + kTP - 1) / kTP), dim3(256), (size_t)kTP * (pre_K | 1) * sizeof(int32_t),
+                         s, m->pre_nbr, p.rows, n, npos_b, pre_K, p.nbrT, p.blkmask, (const int32_t *)total);
+      D3D_LAUNCH_CHECK();
+      m->pre_plan_built = true;
     }
     if (prefetched) D3D_HIP_CHECK(hipEventSynchronize(m->count_ev));
     else D3D_HIP_CHECK(hipStreamSynchronize(s));
     n_active = (int)*(int32_t *)&m->host_words[0];
     for (int d = 0; d < 4; d++) m->in_ext[d] = ((const int32_t *)&m->host_words[0])[1 + d];
     A.used = mark;
+  } else {
+    D3D_HIP_CHECK(fill_ones(tab, sizeof(HashEntry) * g.cap, s));   // an empty grid still answers probes
   }
   g.n = n_active;
   for (int d = 0; d < 4; d++) g.hext[d] = m->in_ext[d];

@@ -129,7 +129,9 @@ struct RoiLevel {
   const HashEntry *tab;   // null: this level is not pooled by the launch
   const float *feats;
   const int32_t *extent;  // occupied extent of the grid on the device, or null: H, W, Z below
+  const int32_t *dense;   // null, or the dense index of the grid's bounding box [b][e0][e1][e2] (1 + site id, 0 = empty)
   int cap, H, W, Z;
+  int e0, e1, e2;
   float scale;
 };
 static constexpr int kRoiMaxLevels = 4;
@@ -148,6 +150,7 @@ __global__ __launch_bounds__(kRoiWaves * 64) __attribute__((amdgpu_waves_per_eu(
   if (l == 3) L = lv.v[3];
   if (!L.tab) return;                         // pooled from another pyramid level (by another launch)
   const HashEntry *__restrict__ tab = L.tab;
+  const int32_t *__restrict__ dense = L.dense;
   const float *__restrict__ feats = L.feats;
   const int cap = L.cap;
   const float spatial_scale = L.scale;
@@ -219,7 +222,21 @@ __global__ __launch_bounds__(kRoiWaves * 64) __attribute__((amdgpu_waves_per_eu(
             }
           }
         }
-        hash_find_n<4>(tab, cap, key, want, r4);
+        if (dense) {       // one load per corner: the cell of the grid's dense index (coordinates are inside the box:
+                           // tri_setup clamps them to the occupied extent, which the box contains)
+          int v4[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const uint64_t kk = key[j];
+            const size_t cell = ((((size_t)(kk >> 48) * L.e0 + (size_t)((kk >> 32) & 0xffff)) * L.e1 +
+                                  (size_t)((kk >> 16) & 0xffff)) * L.e2 + (size_t)(kk & 0xffff));
+            v4[j] = want[j] ? dense[cell] : 0;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; j++) r4[j] = v4[j] - 1;
+        } else {
+          hash_find_n<4>(tab, cap, key, want, r4);
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) row[g0 + j] = r4[j];
       }
@@ -509,7 +526,8 @@ static int roi_level_of(d3d_meta *m, const int *size, const float *feats, const 
     if (rc) return rc;
     extent = g.extent;
   }
-  *lv = {g.tab, feats, extent, g.cap, crop ? crop[0] : 0, crop ? crop[1] : 0, crop ? crop[2] : 0, spatial_scale};
+  *lv = {g.tab, feats, extent, crop ? nullptr : g.dense, g.cap, crop ? crop[0] : 0, crop ? crop[1] : 0, crop ? crop[2] : 0,
+         g.hext[0], g.hext[1], g.hext[2], spatial_scale};
   return D3D_OK;
 }
 
