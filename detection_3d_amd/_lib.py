@@ -129,10 +129,11 @@ _SIGS = {
     "d3d_nms_batched_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "d3d_rotate_nms_3d": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                          ctypes.c_float, vp, vp, c_int_p, vp, ctypes.c_size_t, vp]),
-    "d3d_rotate_nms_3d_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "d3d_rotate_nms_3d_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "d3d_topk_segments": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, c_float_p, c_int_p, vp, ctypes.c_int, vp,
-                                         ctypes.c_float, vp, vp, vp, vp, vp, vp]),
+                                         ctypes.c_float, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]),
+    "d3d_topk_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "d3d_topk_max": (ctypes.c_int, []),
     "d3d_anchors": (ctypes.c_int, [vp, c_int_p, ctypes.POINTER(ctypes.c_float), ctypes.c_int,
                                    ctypes.POINTER(ctypes.c_float), ctypes.c_float, vp, vp]),

@@ -170,10 +170,19 @@ def topk_segments(vals, k, n=None, elem_stride=1, group_stride=0, n_groups=1, ex
     import ctypes
     mv = ctypes.byref(ctypes.c_float(float(min_value))) if min_value is not None else None
     im = _lib.ints(tuple(int(v) for v in idx_map)) if idx_map is not None else None
+    # key scratch: the selection evaluates every element once and re-reads the cached keys with wide loads
+    nbytes = int(lib().d3d_topk_scratch_bytes(int(n), S)) if n >= 8192 else 0
+    buf = None
+    if nbytes:
+        buf = _NMS_SCRATCH.get(("topk",) + _nms_key(dev))
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+            _NMS_SCRATCH[("topk",) + _nms_key(dev)] = buf
     check(lib().d3d_topk_segments(ptr(vals), int(n), int(elem_stride), int(group_stride), int(n_groups), ptr(example),
                                   int(n_examples), k, int(bool(sigmoid)), mv, im, ptr(reg),
                                   int(reg.shape[1]) if reg is not None else 0, ptr(anchors), float(clip), ptr(out["idx32"]),
-                                  ptr(out["idx"]), ptr(out["scores"]), ptr(out["props"]), ptr(out["counts"]), stream_of()))
+                                  ptr(out["idx"]), ptr(out["scores"]), ptr(out["props"]), ptr(out["counts"]), ptr(buf),
+                                  buf.numel() if buf is not None else 0, stream_of()))
     return out
 
 
@@ -190,7 +199,7 @@ def rotate_nms_3d(rbboxes, scores, pre_max_size=None, post_max_size=None, iou_th
     k = n if pre_max_size is None else min(n, int(pre_max_size))
     if k > topk_max():
         raise D3DError(f"rotate_nms_3d: more than {topk_max()} candidates; pass pre_max_size (reference uses 2000)")
-    nbytes = lib().d3d_rotate_nms_3d_scratch_bytes(k)
+    nbytes = lib().d3d_rotate_nms_3d_scratch_bytes(k, n)
     buf = _NMS_SCRATCH.get(_nms_key(dev))
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)

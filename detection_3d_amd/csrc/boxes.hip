@@ -460,8 +460,12 @@ __global__ __launch_bounds__(kEvalThreads) void k_nms_eval(const NmsBox *__restr
     const double ia = quad_inter_f64(rb.q.p, cb.q.p, clip, 64);
     if (!(ia > 0)) continue;
     const double ua = rb.area + cb.area - ia;
-    if (ua > 0 && ia / ua >= (double)thresh)
+    if (ua > 0 && ia / ua >= (double)thresh) {
       atomicOr(&mask[(seg0 + ij.x) * ncb + (ij.y >> 6)], 1ull << (ij.y & 63));
+      // inside a 64-box chunk also the mirrored bit: a row's diagonal word then lists the EARLIER boxes of the chunk that
+      // suppress it too, which lets the sweep resolve a chunk by fixed-point iteration over all lanes (k_nms_sweep_lds)
+      if ((ij.x >> 6) == (ij.y >> 6)) atomicOr(&mask[(seg0 + ij.y) * ncb + (ij.x >> 6)], 1ull << (ij.x & 63));
+    }
   }
 }
 // Greedy sweep by ONE wave: lane w owns word w of the "removed" bit vector.  Per 64-box chunk the
@@ -655,22 +659,18 @@ __global__ __launch_bounds__(kSwThreads) void k_nms_sweep_lds(const unsigned lon
             ~(((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(removed >> 32), c) << 32) |
               (unsigned int)__builtin_amdgcn_readlane((int)removed, c));
         if (nrow < 64) alive &= (1ull << nrow) - 1ull;
-        unsigned long long kept = 0;
-        const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
-#pragma unroll
-        for (int part = 0; part < 4; part++) {
-          unsigned long long d[16];
-#pragma unroll
-          for (int b = 0; b < 16; b++)
-            d[b] = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, part * 16 + b) << 32) |
-                   (unsigned int)__builtin_amdgcn_readlane((int)dlo, part * 16 + b);
-#pragma unroll
-          for (int b = 0; b < 16; b++) {
-            const unsigned long long bit = 1ull << (part * 16 + b);
-            const bool on = (alive & bit) != 0;
-            kept |= on ? bit : 0ull;
-            alive &= on ? ~d[b] : ~0ull;
-          }
+        // The chunk's greedy decision by fixed-point iteration over all lanes: box b is kept iff it is alive and no KEPT
+        // earlier box of the chunk suppresses it.  K <- { b alive : (sup[b] & K) == 0 } starting from K = alive settles
+        // box 0 after one step, box b once every earlier box is settled -- at most 64 steps, in practice the depth of
+        // the longest suppression chain (a few) -- and its only fixed point is the greedy set.  One ballot per step
+        // instead of a 64-step scalar chain fed by 128 lane reads.
+        const unsigned long long sup = diag & lt;                 // earlier boxes of the chunk that suppress box `lane`
+        const bool my_alive = (alive >> lane) & 1ull;
+        unsigned long long kept = alive;
+        for (int it = 0; it < 65; it++) {
+          const unsigned long long knew = __ballot(my_alive && (sup & kept) == 0ull);
+          if (knew == kept) break;
+          kept = knew;
         }
         // removed |= rows of the kept boxes (word `lane`): 16 LDS reads in flight at a time
         const unsigned long long *col = slot + min(lane, ncb - 1);

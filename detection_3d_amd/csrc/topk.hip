@@ -43,6 +43,9 @@ struct TopkArgs {
   float *scores;
   float *props;             // [S, k, 7]
   int32_t *counts;          // [S] = min(k, elements of the segment)
+  uint32_t *keys;           // null, or scratch [S, n4] (n4 = n rounded up to 4): the ordered keys, written by the first pass
+                            // and re-read by the later ones with 16-byte loads (elements of other examples: key 0)
+  int n4;
 };
 
 __device__ __forceinline__ float topk_value(const TopkArgs &a, int i, int g) {
@@ -95,57 +98,115 @@ __global__ __launch_bounds__(kTopkThreads) void k_topk_select(TopkArgs a) {
   const int n = a.n;
   auto valid = [&](int i) { return a.example == nullptr || a.example[i] == b; };
 
-  // elements of the segment
+  // Key of element i: the order-preserving image of its value, at least 1; 0 marks an element of another example.
+  // With key scratch the values are read (and the sigmoid evaluated) ONCE: the first pass stores the keys, the later
+  // ones re-read them four per 16-byte load with 16 loads in flight per thread -- one workgroup walking ~10^5 elements
+  // one dependent load at a time is bound by that load's latency (measured: 100 us for 150 k anchors, all four passes).
+  uint32_t *const kbuf = a.keys ? a.keys + (size_t)seg * a.n4 : nullptr;
+  auto key_of = [&](int i) -> uint32_t {
+    if (!valid(i)) return 0u;
+    return max(f32_ordered(topk_value(a, i, g)), 1u);
+  };
+  // f(key, index) over all elements, in batches of independent loads
+  auto for_each_key = [&](auto f) {
+    if (kbuf) {
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      constexpr int U = 4;
+      const int nq = a.n4 / 4;                                  // 16-byte groups
+      for (int q0 = 0; q0 < nq; q0 += kTopkThreads * U) {
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int q = q0 + u * kTopkThreads + tid;
+          v[u] = q < nq ? *(const u32x4 *)(kbuf + (size_t)q * 4) : (u32x4){0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int q = q0 + u * kTopkThreads + tid;
+#pragma unroll
+          for (int j = 0; j < 4; j++) f(v[u][j], q * 4 + j);
+        }
+      }
+    } else {
+      for (int i0 = 0; i0 < n; i0 += kTopkThreads) {
+        const int i = i0 + tid;
+        f(i < n ? key_of(i) : 0u, i);
+      }
+    }
+  };
+  // wave-aggregated histogram add: the lanes that share the first active lane's bin add once, together (scores of one
+  // map crowd into few bins -- a random-init head puts every sigmoid next to 0.5 -- and 64 lanes adding to one LDS word
+  // serialise)
+  auto hist_add = [&](bool in, uint32_t bin) {
+    const unsigned long long todo = __ballot(in);
+    if (todo) {
+      const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, __builtin_ctzll(todo));
+      const unsigned long long same = __ballot(in && bin == b0);
+      if (lane == (int)__builtin_ctzll(same)) atomicAdd(&hist[b0], (uint32_t)__popcll(same));
+      if (in && bin != b0) atomicAdd(&hist[bin], 1u);
+    }
+  };
+
   if (tid == 0) {
     n_valid_s = 0;
     n_sel = 0;
   }
+  for (int i = tid; i < 2048; i += kTopkThreads) hist[i] = 0;
   __syncthreads();
-  if (a.example) {
+  // pass 0: keys (stored when there is scratch), the segment's element count and the first histogram (bits 31..21)
+  {
     uint32_t c = 0;
-    for (int i = tid; i < n; i += kTopkThreads) c += valid(i) ? 1u : 0u;
+    if (kbuf) {
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      const int nq = a.n4 / 4;
+      for (int q = tid; q < nq; q += kTopkThreads) {
+        u32x4 kv;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int i = q * 4 + j;
+          kv[j] = i < n ? key_of(i) : 0u;
+        }
+        *(u32x4 *)(kbuf + (size_t)q * 4) = kv;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          c += kv[j] != 0u;
+          hist_add(kv[j] != 0u, kv[j] >> 21);
+        }
+      }
+    } else {
+      for (int i0 = 0; i0 < n; i0 += kTopkThreads) {
+        const int i = i0 + tid;
+        const uint32_t key = i < n ? key_of(i) : 0u;
+        c += key != 0u;
+        hist_add(key != 0u, key >> 21);
+      }
+    }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
     if (lane == 0 && c) atomicAdd(&n_valid_s, c);
-  } else if (tid == 0) {
-    n_valid_s = (uint32_t)n;
   }
   __syncthreads();
   const int k_eff = min(a.k, (int)n_valid_s);
   if (tid == 0 && a.counts && (!a.use_min || k_eff == 0)) a.counts[seg] = k_eff;
   if (k_eff == 0) return;
 
-  // 1. the k_eff-th largest key: three radix levels
+  // 1. the k_eff-th largest key: three radix levels (11 + 11 + 10 bits); the first histogram is pass 0's
   uint32_t prefix = 0, want = (uint32_t)k_eff;
-  const int shifts[3] = {21, 10, 0};
-  const int nbits[3] = {11, 11, 10};
+  find_bin_from_top<2048>(hist, want, wtot, pick);
+  prefix = pick[0] << 21;
+  want = pick[1];
+  __syncthreads();
 #pragma unroll
-  for (int level = 0; level < 3; level++) {
-    const int shift = shifts[level], nb = 1 << nbits[level];
-    const uint32_t fixed_mask = level == 0 ? 0u : (0xffffffffu << (shift + nbits[level]));
+  for (int level = 1; level < 3; level++) {
+    const int shift = level == 1 ? 10 : 0, bits = level == 1 ? 11 : 10;
+    const uint32_t fixed_mask = 0xffffffffu << (shift + bits);
     for (int i = tid; i < 2048; i += kTopkThreads) hist[i] = 0;
     __syncthreads();
-    // (scores of one map crowd into few bins -- a random-init head puts every sigmoid next to 0.5 -- and 64 lanes adding to
-    //  one LDS word serialise: the lanes of a wave that share the first active lane's bin add once, together)
-    for (int i0 = 0; i0 < n; i0 += kTopkThreads) {
-      const int i = i0 + tid;
-      bool in = false;
-      uint32_t bin = 0;
-      if (i < n && valid(i)) {
-        const uint32_t key = f32_ordered(topk_value(a, i, g));
-        in = (key & fixed_mask) == prefix;
-        bin = (key >> shift) & (uint32_t)(nb - 1);
-      }
-      unsigned long long todo = __ballot(in);
-      if (todo) {
-        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, __builtin_ctzll(todo));
-        const unsigned long long same = __ballot(in && bin == b0);
-        if (lane == (int)__builtin_ctzll(same)) atomicAdd(&hist[b0], (uint32_t)__popcll(same));
-        if (in && bin != b0) atomicAdd(&hist[bin], 1u);
-      }
-    }
+    for_each_key([&](uint32_t key, int) {
+      hist_add(key != 0u && (key & fixed_mask) == prefix, (key >> shift) & ((1u << bits) - 1u));
+    });
     __syncthreads();
-    if (level < 2) find_bin_from_top<2048>(hist, want, wtot, pick);
+    if (level == 1) find_bin_from_top<2048>(hist, want, wtot, pick);
     else find_bin_from_top<1024>(hist, want, wtot, pick);
     prefix |= pick[0] << shift;
     want = pick[1];
@@ -158,20 +219,19 @@ __global__ __launch_bounds__(kTopkThreads) void k_topk_select(TopkArgs a) {
 
   // 2. collect: keys above T (any order -- the sort follows) and the need_eq lowest-index keys equal to T
   const bool all_ties = n_eq == need_eq;
-  for (int i = tid; i < n; i += kTopkThreads) {
-    if (!valid(i)) continue;
-    const uint32_t key = f32_ordered(topk_value(a, i, g));
-    if (key > T || (all_ties && key == T)) {
+  for_each_key([&](uint32_t key, int i) {
+    if (key > T || (all_ties && key == T && key != 0u)) {
       const uint32_t p = atomicAdd(&n_sel, 1u);
       sel[p] = ((unsigned long long)key << 32) | (uint32_t)(~(uint32_t)i);
     }
-  }
+  });
   if (!all_ties) {
     // ties at the threshold: thread t owns the contiguous index range [t * per, t * per + per); ranks by a workgroup scan
     const int per = (n + kTopkThreads - 1) / kTopkThreads;
     const int i0 = min(n, tid * per), i1 = min(n, i0 + per);
+    auto key_at = [&](int i) -> uint32_t { return kbuf ? kbuf[i] : key_of(i); };
     uint32_t mine = 0;
-    for (int i = i0; i < i1; i++) mine += (valid(i) && f32_ordered(topk_value(a, i, g)) == T) ? 1u : 0u;
+    for (int i = i0; i < i1; i++) mine += key_at(i) == T ? 1u : 0u;
     uint32_t inc = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -184,7 +244,7 @@ __global__ __launch_bounds__(kTopkThreads) void k_topk_select(TopkArgs a) {
     uint32_t rank = inc - mine;
     for (int w = 0; w < wave; w++) rank += wtot[w];
     for (int i = i0; i < i1 && rank < need_eq; i++) {
-      if (valid(i) && f32_ordered(topk_value(a, i, g)) == T) {
+      if (key_at(i) == T) {
         const uint32_t p = atomicAdd(&n_sel, 1u);
         sel[p] = ((unsigned long long)T << 32) | (uint32_t)(~(uint32_t)i);
         rank++;
@@ -258,11 +318,15 @@ using namespace d3d;
 extern "C" {
 
 int d3d_topk_max(void) { return kTopkMax; }
+size_t d3d_topk_scratch_bytes(int n, int segments) {
+  return (size_t)std::max(segments, 0) * (size_t)((std::max(n, 0) + 3) & ~3) * sizeof(uint32_t);
+}
 
 int d3d_topk_segments(const float *vals, int n, int elem_stride, int group_stride, int n_groups, const int32_t *example,
                       int n_examples, int k, int apply_sigmoid, const float *min_value_host, const int *idx_map_host,
                       const float *reg, int reg_stride, const float *anchors, float clip, int32_t *idx32_out,
-                      int64_t *idx64_out, float *scores_out, float *props_out, int32_t *counts_out, void *stream) {
+                      int64_t *idx64_out, float *scores_out, float *props_out, int32_t *counts_out, void *scratch,
+                      size_t scratch_bytes, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   D3D_REQUIRE(n >= 0 && n_groups >= 1 && n_examples >= 1 && elem_stride >= 1 && group_stride >= 0, "topk: bad shape");
   D3D_REQUIRE(k >= 0 && k <= kTopkMax, "topk: k = %d (at most %d)", k, kTopkMax);
@@ -286,14 +350,18 @@ int d3d_topk_segments(const float *vals, int n, int elem_stride, int group_strid
   a.k = k; a.apply_sigmoid = apply_sigmoid;
   a.reg = reg; a.reg_stride = reg_stride; a.anchors = anchors; a.clip = clip;
   a.idx32 = idx32_out; a.idx64 = idx64_out; a.scores = scores_out; a.props = props_out; a.counts = counts_out;
+  a.n4 = (n + 3) & ~3;
+  a.keys = (scratch && scratch_bytes >= d3d_topk_scratch_bytes(n, S) && ((uintptr_t)scratch & 15) == 0) ? (uint32_t *)scratch
+                                                                                                         : nullptr;
   hipLaunchKernelGGL(k_topk_select, dim3(S), dim3(kTopkThreads), 0, s, a);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }
 
-size_t d3d_rotate_nms_3d_scratch_bytes(int pre_max_size) {
+// (n: the number of input boxes -- the selection keeps their keys in the scratch; 0: without, slower for large n)
+size_t d3d_rotate_nms_3d_scratch_bytes(int pre_max_size, int n) {
   const int k = std::max(0, std::min(pre_max_size, kTopkMax));
-  return d3d_nms_batched_scratch_bytes(1, k) + (size_t)k * 8 + 1024;
+  return d3d_nms_batched_scratch_bytes(1, k) + (size_t)k * 8 + 1024 + 512 + d3d_topk_scratch_bytes(n, 1);
 }
 
 // rotate_nms_3d as the reference defines it (box_torch_ops.py:489-514 behind boxlist_nms_3d's size clamp,
@@ -313,15 +381,19 @@ int d3d_rotate_nms_3d(const float *boxes, const float *scores, int n, int pre_ma
     D3D_HIP_CHECK(hipMemsetAsync(n_keep_dev, 0, sizeof(int32_t), s));
     return D3D_OK;
   }
-  D3D_REQUIRE(boxes && scores && keep_out && scratch && scratch_bytes >= d3d_rotate_nms_3d_scratch_bytes(k),
+  D3D_REQUIRE(boxes && scores && keep_out && scratch && scratch_bytes >= d3d_rotate_nms_3d_scratch_bytes(k, 0),
               "rotate_nms_3d: bad buffers");
   char *base = (char *)scratch;
   int32_t *order = (int32_t *)base;                       // [k] candidates, descending score
   int32_t *keep32 = order + k;                            // [k]
   int32_t *cnt = keep32 + k;                              // [1] candidates (= k)
   const size_t off = (((size_t)k * 8 + 64) + 255) & ~size_t(255);
+  // (key scratch for the selection: what lies behind the NMS's own scratch, if the caller provided that much)
+  const size_t nms_bytes = d3d_nms_batched_scratch_bytes(1, k);
+  const size_t key_off = (off + nms_bytes + 255) & ~size_t(255);
+  void *key_scratch = scratch_bytes >= key_off + d3d_topk_scratch_bytes(n, 1) ? base + key_off : nullptr;
   int rc = d3d_topk_segments(scores, n, 1, 0, 1, nullptr, 1, k, 0, nullptr, nullptr, nullptr, 0, nullptr, 0.f, order, nullptr,
-                             nullptr, nullptr, cnt, stream);
+                             nullptr, nullptr, cnt, key_scratch, key_scratch ? d3d_topk_scratch_bytes(n, 1) : 0, stream);
   if (rc) return rc;
   rc = d3d_rotate_nms_3d_batched(boxes, order, k, cnt, 1, k, thresh, aug_yx, aug_z, post_max_size > 0 ? post_max_size : 0,
                                  keep32, n_keep_dev, base + off, scratch_bytes - off, stream);

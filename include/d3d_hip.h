@@ -412,11 +412,12 @@ int d3d_rotate_nms_3d_batched(const float *boxes, const int32_t *order, int stri
  * it is defined.  Sizes clamped for the IoU only (dy, dx >= aug_yx, dz >= aug_z); greedy rotated NMS at `thresh`; at
  * most post_max_size survivors (<= 0: all).  keep_out int64 [min(n, pre_max_size)] = indices into the input in selection
  * order (the LongTensor the reference returns); n_keep_dev device int32 [1]; n_keep_host (NULL: no read-back) receives
- * the count after one stream synchronisation.  scratch >= d3d_rotate_nms_3d_scratch_bytes(pre_max_size).            */
+ * the count after one stream synchronisation.  scratch >= d3d_rotate_nms_3d_scratch_bytes(pre_max_size, 0); with
+ * d3d_rotate_nms_3d_scratch_bytes(pre_max_size, n) bytes the selection also caches its keys there (faster for large n). */
 int d3d_rotate_nms_3d(const float *boxes, const float *scores, int n, int pre_max_size, int post_max_size, float thresh,
                       float aug_yx, float aug_z, int64_t *keep_out, int32_t *n_keep_dev, int *n_keep_host, void *scratch,
                       size_t scratch_bytes, void *stream);
-size_t d3d_rotate_nms_3d_scratch_bytes(int pre_max_size);
+size_t d3d_rotate_nms_3d_scratch_bytes(int pre_max_size, int n);   /* n = input boxes (0: no key scratch, slower selection) */
 /* a13. The selection of RPNPostProcessor.forward_for_single_feature_map (modeling/rpn/inference_3d.py:105-123), and of
  * the per-class candidate lists of the box head's post-processing (roi_heads/box_head_3d/inference.py:113-131), for
  * n_examples x n_groups segments in ONE launch.  Segment s = example * n_groups + group reads element i at
@@ -431,7 +432,11 @@ size_t d3d_rotate_nms_3d_scratch_bytes(int pre_max_size);
 int d3d_topk_segments(const float *vals, int n, int elem_stride, int group_stride, int n_groups, const int32_t *example,
                       int n_examples, int k, int apply_sigmoid, const float *min_value_host, const int *idx_map_host,
                       const float *reg, int reg_stride, const float *anchors, float clip, int32_t *idx32_out,
-                      int64_t *idx64_out, float *scores_out, float *props_out, int32_t *counts_out, void *stream);
+                      int64_t *idx64_out, float *scores_out, float *props_out, int32_t *counts_out, void *scratch,
+                      size_t scratch_bytes, void *stream);
+/* scratch (may be NULL; 16-byte aligned, >= d3d_topk_scratch_bytes(n, segments)): the selection then evaluates every
+ * element once and re-reads cached keys with wide loads in its later passes (several times faster for n ~ 10^5).      */
+size_t d3d_topk_scratch_bytes(int n, int segments);
 int d3d_topk_max(void);
 size_t d3d_nms_batched_scratch_bytes(int segments, int n_max);
 /* Box-head post-processing glue around the batched NMS (roi_heads/box_head_3d/inference.py:113-148), one launch each:
