@@ -137,12 +137,26 @@ __global__ __launch_bounds__(kTopkThreads) void k_topk_select(TopkArgs a) {
   // wave-aggregated histogram add: the lanes that share the first active lane's bin add once, together (scores of one
   // map crowd into few bins -- a random-init head puts every sigmoid next to 0.5 -- and 64 lanes adding to one LDS word
   // serialise)
+  // A wave counts the run of elements that fall into ONE bin in scalar registers (wbin, wcnt) and adds to the LDS
+  // histogram only when the bin changes (hist_flush at the end of a pass): with crowded scores a pass costs a wave a
+  // handful of LDS atomics instead of one per 64 elements, all of them on the same word.
+  uint32_t wbin = 0xffffffffu, wcnt = 0;
+  auto hist_flush = [&]() {
+    if (wcnt && lane == 0) atomicAdd(&hist[wbin], wcnt);
+    wcnt = 0;
+    wbin = 0xffffffffu;
+  };
   auto hist_add = [&](bool in, uint32_t bin) {
     const unsigned long long todo = __ballot(in);
     if (todo) {
       const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, __builtin_ctzll(todo));
       const unsigned long long same = __ballot(in && bin == b0);
-      if (lane == (int)__builtin_ctzll(same)) atomicAdd(&hist[b0], (uint32_t)__popcll(same));
+      if (b0 != wbin) {
+        if (wcnt && lane == 0) atomicAdd(&hist[wbin], wcnt);
+        wbin = b0;
+        wcnt = 0;
+      }
+      wcnt += (uint32_t)__popcll(same);
       if (in && bin != b0) atomicAdd(&hist[bin], 1u);
     }
   };
@@ -158,19 +172,35 @@ __global__ __launch_bounds__(kTopkThreads) void k_topk_select(TopkArgs a) {
     uint32_t c = 0;
     if (kbuf) {
       typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      constexpr int U = 4;                                      // 16 independent value loads in flight per thread
       const int nq = a.n4 / 4;
-      for (int q = tid; q < nq; q += kTopkThreads) {
-        u32x4 kv;
+      for (int q0 = 0; q0 < nq; q0 += kTopkThreads * U) {
+        float x[U][4];
+        bool ok[U][4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int i = q * 4 + j;
-          kv[j] = i < n ? key_of(i) : 0u;
-        }
-        *(u32x4 *)(kbuf + (size_t)q * 4) = kv;
+        for (int u = 0; u < U; u++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          c += kv[j] != 0u;
-          hist_add(kv[j] != 0u, kv[j] >> 21);
+          for (int j = 0; j < 4; j++) {
+            const int i = (q0 + u * kTopkThreads + tid) * 4 + j;
+            ok[u][j] = i < n && valid(i);
+            x[u][j] = ok[u][j] ? a.vals[(size_t)g * a.group_stride + (size_t)i * a.elem_stride] : 0.f;
+          }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int q = q0 + u * kTopkThreads + tid;
+          u32x4 kv;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            float v = x[u][j];
+            if (a.apply_sigmoid) v = 1.0f / (1.0f + expf(-v));
+            kv[j] = ok[u][j] ? max(f32_ordered(v), 1u) : 0u;
+          }
+          if (q < nq) *(u32x4 *)(kbuf + (size_t)q * 4) = kv;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            c += kv[j] != 0u;
+            hist_add(kv[j] != 0u, kv[j] >> 21);
+          }
         }
       }
     } else {
@@ -181,6 +211,7 @@ __global__ __launch_bounds__(kTopkThreads) void k_topk_select(TopkArgs a) {
         hist_add(key != 0u, key >> 21);
       }
     }
+    hist_flush();
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
     if (lane == 0 && c) atomicAdd(&n_valid_s, c);
@@ -205,6 +236,7 @@ __global__ __launch_bounds__(kTopkThreads) void k_topk_select(TopkArgs a) {
     for_each_key([&](uint32_t key, int) {
       hist_add(key != 0u && (key & fixed_mask) == prefix, (key >> shift) & ((1u << bits) - 1u));
     });
+    hist_flush();
     __syncthreads();
     if (level == 1) find_bin_from_top<2048>(hist, want, wtot, pick);
     else find_bin_from_top<1024>(hist, want, wtot, pick);

@@ -26,7 +26,8 @@ ASYNC_GEOMETRY = os.environ.get("D3D_ASYNC_GEOMETRY", "1") != "0"   # the grid c
 ASYNC_VIEWS = os.environ.get("D3D_ASYNC_VIEWS", "1") != "0"         # ... and that thread also enqueues the views (third stream)
 SIDE_START = os.environ.get("D3D_SIDE_START", "scene")              # "main": side streams wait for the caller's stream at the
                     # input grid (and the point lists go to the geometry stream), as before the grid chain -- A/B runs
-_GEO_STREAMS = {}   # (device, caller's stream) -> high-priority side streams
+_GEO_STREAMS = {}   # (device, caller's stream) -> side streams
+_SIDE_PRIORITY = int(os.environ.get("D3D_SIDE_PRIORITY", "-1"))     # -1: high (geometry ahead of the convolutions), 0: normal
 
 
 def _is_gpu_input(net0):
@@ -38,9 +39,9 @@ def _geometry_stream(main):
     key = (main.device.index, main.cuda_stream)
     st = _GEO_STREAMS.get(key)
     if st is None:
-        st = _GEO_STREAMS[key] = (torch.cuda.Stream(device=main.device, priority=-1),
+        st = _GEO_STREAMS[key] = (torch.cuda.Stream(device=main.device, priority=_SIDE_PRIORITY),
                                   [torch.cuda.Event() for _ in range(16)],
-                                  torch.cuda.Stream(device=main.device, priority=-1),
+                                  torch.cuda.Stream(device=main.device, priority=_SIDE_PRIORITY),
                                   [torch.cuda.Event() for _ in range(16)])
     return st
 
