@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libd3d_hip.so")
-SOURCES = ["grid.hip", "conv.hip", "conv_bf16.hip", "bn.hip", "boxes.hip", "roi_align.hip", "backward.hip", "rpn_head.hip", "topk.hip"]
+SOURCES = ["grid.hip", "conv.hip", "conv_ws.hip", "conv_bf16.hip", "bn.hip", "boxes.hip", "roi_align.hip", "backward.hip", "rpn_head.hip", "topk.hip"]
 # -ffp-contract=off: the box geometry shares an arithmetic contract with the CPU oracle
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-std=c++17"]
 

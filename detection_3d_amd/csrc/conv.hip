@@ -433,7 +433,9 @@ static int launch_t(d3d_meta *m, const Plan &p, const float *in, int cin, const 
   const hipEvent_t ev_start = t_time_start, ev_stop = t_time_stop;
   t_time_start = t_time_stop = nullptr;
   if (ev_start) (void)hipEventRecord(ev_start, s);
-  if (cin == CT * NCT)
+  if (cin == CT * NCT && n_split == 1 && launch_conv_ws(p, in, cin, wp, COUT, residual, out, s, pre, stat, in_bytes)) {
+    // (taken by the weight-sharing kernel: same products in the same order)
+  } else if (cin == CT * NCT)
     hipLaunchKernelGGL((k_conv<CT, NCT, COUT, NT, BPW, true>), grid, dim3(threads), 0, s, in, cin, wp, p.nbrT, npos,
                        p.rows, p.blkmask, p.n_blk, residual, out, n_split, partial, pre, in_bytes,
                        n_split > 1 ? nullptr : stat);

@@ -238,6 +238,9 @@ int launch_conv_bf16(d3d_meta *m, const Plan &p, const void *in, int cin, const 
                      const void *residual, void *out, hipStream_t s, const d3d_bn_prologue *bn);
 int launch_conv(d3d_meta *m, const Plan &p, const float *in, int cin, const float *packed_w, int cout,
                 const float *residual, float *out, hipStream_t s, const d3d_bn_prologue *bn = nullptr);
+// conv_ws.hip: the weight-sharing kernel for the large launches of the wide layers; false = not taken
+bool launch_conv_ws(const Plan &p, const float *in, int cin, const float *wp, int cout, const float *residual, float *out,
+                    hipStream_t s, BnPre pre, double *stat, uint32_t in_bytes);
 
 __device__ __forceinline__ uint64_t pack_key(int b, int x, int y, int z) {
   return ((uint64_t)(uint16_t)b << 48) | ((uint64_t)(uint16_t)x << 32) |

@@ -58,6 +58,11 @@ int d3d_meta_set_geometry_stream(d3d_meta *m, void *stream, int enable);
  * read-back between the levels (1, default; grid.hip run_grid_chain) or one d3d_conv_prepare call -- and read-back -- per
  * level (0).  Same results.  -> the previous setting.  Also settable through the environment: D3D_GRID_CHAIN=0.        */
 int d3d_grid_chain_enable(int on);
+/* Measurement / A-B switch of the fp32 sparse convolutions: 0 = every launch through k_conv; 1 (default) = the large
+ * launches of the 64 -> 64 and 128 -> 128 layers through the weight-sharing kernel (conv_ws.hip); 2 = those layers'
+ * launches of every size (tests).  Same results bit for bit.  mode < 0: query only.  -> the previous setting.
+ * Environment: D3D_CONV_WS.                                                                                          */
+int d3d_conv_ws_mode(int mode);
 /* ... and how many of the leading levels form a chain (and read-back) of their own before the chain over the rest (default
  * 1: the first strided grid is wanted long before a chain over all levels ends; 0: one chain).  -> previous setting.   */
 int d3d_grid_chain_head(int levels);
