@@ -61,7 +61,13 @@ __global__ void k_pack_weight(const float *__restrict__ w, int fv, int cin, int 
 // the gather costs as few VALU instructions as possible: wave-uniform (scalar) base pointers + 32-bit per-lane byte
 // offsets, one multiplier per row (1 = real, 0 = absent neighbour) instead of per-element selects, fused multiply-add
 // + max for the BatchNorm + ReLU prologue.
-template <int CT, int NCT, int COUT, int NT, int BPW, bool VEC>
+// LATE = the next step's gather (and index) loads are issued after the step's FIRST q-iteration instead of ahead of its matrix
+//        work, branch-free (a step without successor requests absent rows).  The compiler's s_waitcnt placement is
+//        conservative at the loop header: the wait in front of the step's first MFMA -- for weight fragments requested a
+//        step ago -- also covered every load issued since, i.e. the gathers just requested: each step began with the
+//        wave stalled for a full gather round trip.  Issued behind the first MFMAs, only loads of the previous step are
+//        outstanding at that wait, and the counted waits inside the straight-line q-loop leave the gathers in flight.
+template <int CT, int NCT, int COUT, int NT, int BPW, bool VEC, bool LATE = false>
 __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
     const float *__restrict__ in, int cin, const float *__restrict__ wp,
     const int32_t *__restrict__ nbrT, int npos, const int32_t *__restrict__ rows,
@@ -238,10 +244,12 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
       nct = 0;
       nk = next_k(k);
     }
-    if (nk >= 0) {
-      issue_data(nct);  // loads fly while the matrix cores work; idx holds offset nk
-      const int k2 = (nct + 1 < NCT) ? nk : next_k(nk);   // the step after that: its indices are requested now
-      if (k2 >= 0 && k2 != nk) load_idx(k2);
+    const int k2 = nk < 0 ? -1 : ((nct + 1 < NCT) ? nk : next_k(nk));   // the step after that: its indices are requested now
+    if constexpr (!LATE) {
+      if (nk >= 0) {
+        issue_data(nct);  // loads fly while the matrix cores work; idx holds offset nk
+        if (k2 >= 0 && k2 != nk) load_idx(k2);
+      }
     }
     __builtin_amdgcn_s_setprio(1);
     // ---- 32 x (NT*32) += A[32 x CT] * W[k][CT x cols] ----
@@ -267,17 +275,43 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[nt][2], acc[nt], 0, 0, 0);
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[nt][3], acc[nt], 0, 0, 0);
       }
+      if constexpr (LATE) {
+        if (q == 0) {
+          // branch-free: without a next step the rows asked for are absent ones (zeros from the range check, never
+          // committed), and the index loads repeat offset k's
+          if (nk < 0) {
+#pragma unroll
+            for (int it = 0; it < NIT; it++) idx[it] = -1;
+          }
+          issue_data(nk >= 0 ? nct : 0);
+          load_idx(k2 >= 0 ? k2 : k);
+        }
+      }
     }
     // order of the step's instruction stream: the gather / index loads up front, then per q-iteration one MFMA,
     // one LDS read (A of the next iteration), one weight load (ring refill QA iterations ahead), the other MFMAs
-    __builtin_amdgcn_sched_group_barrier(0x020, 2 * NIT, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    if constexpr (!LATE) {
+      __builtin_amdgcn_sched_group_barrier(0x020, 2 * NIT, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, NT, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT - 1, 0);
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, NT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT - 1, 0);
+      }
+    } else {
+      // LATE: A of q = 0, its first MFMA, A of q = 1, the ring refill, the other MFMAs of q = 0, THEN the gather and
+      // index loads, then the remaining q-iterations as above
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, NT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT - 1, 0);
+        if (q == 0) __builtin_amdgcn_sched_group_barrier(0x020, 2 * NIT, 0);
+      }
     }
     __builtin_amdgcn_s_setprio(0);
     block_sync();
@@ -389,6 +423,10 @@ __global__ __launch_bounds__(256) void k_conv_reduce(const float *__restrict__ p
 }
 
 static constexpr int kSplitTargetWaves = 4096;  // below this many waves the launch is offset-split
+static bool g_conv_late = [] {            // D3D_CONV_LATE=0: gathers issued ahead of the step's matrix work (A/B runs)
+  const char *e = getenv("D3D_CONV_LATE");
+  return !(e && e[0] == '0');
+}();
 
 // d3d_conv_time_next: HIP events the next k_conv launch of this thread is bracketed with (measurement only)
 static thread_local hipEvent_t t_time_start = nullptr, t_time_stop = nullptr;
@@ -435,7 +473,11 @@ static int launch_t(d3d_meta *m, const Plan &p, const float *in, int cin, const 
   if (ev_start) (void)hipEventRecord(ev_start, s);
   if (cin == CT * NCT && n_split == 1 && launch_conv_ws(p, in, cin, wp, COUT, residual, out, s, pre, stat, in_bytes)) {
     // (taken by the weight-sharing kernel: same products in the same order)
-  } else if (cin == CT * NCT)
+  } else if (cin == CT * NCT && g_conv_late && CT >= 32)
+    hipLaunchKernelGGL((k_conv<CT, NCT, COUT, NT, BPW, true, true>), grid, dim3(threads), 0, s, in, cin, wp, p.nbrT, npos,
+                       p.rows, p.blkmask, p.n_blk, residual, out, n_split, partial, pre, in_bytes,
+                       n_split > 1 ? nullptr : stat);
+  else if (cin == CT * NCT)
     hipLaunchKernelGGL((k_conv<CT, NCT, COUT, NT, BPW, true>), grid, dim3(threads), 0, s, in, cin, wp, p.nbrT, npos,
                        p.rows, p.blkmask, p.n_blk, residual, out, n_split, partial, pre, in_bytes,
                        n_split > 1 ? nullptr : stat);
@@ -507,6 +549,12 @@ int launch_conv(d3d_meta *m, const Plan &p, const float *in, int cin, const floa
 using namespace d3d;
 
 extern "C" {
+
+int d3d_conv_late_mode(int on) {
+  const int was = g_conv_late ? 1 : 0;
+  if (on >= 0) g_conv_late = on != 0;
+  return was;
+}
 
 int d3d_conv_time_next(void *start_event, void *stop_event) {
   t_time_start = (hipEvent_t)start_event;

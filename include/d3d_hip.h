@@ -63,6 +63,9 @@ int d3d_grid_chain_enable(int on);
  * launches of every size (tests).  Same results bit for bit.  mode < 0: query only.  -> the previous setting.
  * Environment: D3D_CONV_WS.                                                                                          */
 int d3d_conv_ws_mode(int mode);
+/* ... and whether k_conv requests the next step's gathered rows behind the step's first MFMAs (1, default) or ahead of its
+ * matrix work (0).  Same results.  on < 0: query only.  -> previous setting.  Environment: D3D_CONV_LATE.              */
+int d3d_conv_late_mode(int on);
 /* ... and how many of the leading levels form a chain (and read-back) of their own before the chain over the rest (default
  * 1: the first strided grid is wanted long before a chain over all levels ends; 0: one chain).  -> previous setting.   */
 int d3d_grid_chain_head(int levels);

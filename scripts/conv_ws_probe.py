@@ -29,8 +29,15 @@ with torch.no_grad():
         same = [torch.equal(a, b) for a, b in zip(outs[0], outs[mode])]
         err = [((a - b).abs().max() / a.abs().max()).item() for a, b in zip(outs[0], outs[mode])]
         print(f"mode {mode} vs k_conv: identical {same}  rel err {['%.2g' % e for e in err]}")
-    for mode in (0, 1, 0, 1):
+    lib().d3d_conv_late_mode(0)
+    lib().d3d_conv_ws_mode(0)
+    ref = [t.features.clone() for t in sum(model.backbone([coords, feats]), [])]
+    lib().d3d_conv_late_mode(1)
+    got = [t.features.clone() for t in sum(model.backbone([coords, feats]), [])]
+    print("late gathers vs early: identical", [torch.equal(a, b) for a, b in zip(ref, got)])
+    for mode, late in ((0, 0), (0, 1), (1, 1), (0, 0), (0, 1), (1, 1)):
         lib().d3d_conv_ws_mode(mode)
+        lib().d3d_conv_late_mode(late)
         prof = SCN.ConvProfiler()
         SCN.set_profiler(prof)
         prof.start_scene("s", True)
@@ -46,4 +53,4 @@ with torch.no_grad():
         tot = sum(v["ms"] for v in summ.values()) / 10
         parts = "  ".join(f"{k}: {v['ms'] / 10:.3f} ms {v['flops'] / (v['ms'] * 1e-3) / 1e12:.0f} TF"
                           for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:5])
-        print(f"ws mode {mode}: all sparse convs {tot:.3f} ms per building | {parts}")
+        print(f"ws {mode} late {late}: all sparse convs {tot:.3f} ms per building | {parts}")
