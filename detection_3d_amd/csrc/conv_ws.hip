@@ -230,9 +230,13 @@ __global__ __launch_bounds__(RBW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
 }
 
-static int g_ws_mode = [] {               // D3D_CONV_WS: 0 off, 1 on (default), 2 on for every launch size (tests)
+// D3D_CONV_WS: 0 off (default), 1 on for the large launches, 2 on for every launch size (tests).  Measured on the
+// 500 k-point building (scripts/conv_ws_probe.py, ms per building): 64 -> 64 0.83 with k_conv against 0.97 here, 128 -> 128
+// 1.36-1.43 against 1.37-1.38 -- the weight fetch is not what holds k_conv back, and the lockstep of four row blocks over
+// the union of their offset masks costs the narrow layer more than the shared fetch saves.  Kept as a measured variant.
+static int g_ws_mode = [] {
   const char *e = getenv("D3D_CONV_WS");
-  return e ? atoi(e) : 1;
+  return e ? atoi(e) : 0;
 }();
 static constexpr int kWsMinBlocks = 2048;  // launches below this stay with k_conv (offset-split / latency-bound there)
 

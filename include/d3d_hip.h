@@ -58,9 +58,9 @@ int d3d_meta_set_geometry_stream(d3d_meta *m, void *stream, int enable);
  * read-back between the levels (1, default; grid.hip run_grid_chain) or one d3d_conv_prepare call -- and read-back -- per
  * level (0).  Same results.  -> the previous setting.  Also settable through the environment: D3D_GRID_CHAIN=0.        */
 int d3d_grid_chain_enable(int on);
-/* Measurement / A-B switch of the fp32 sparse convolutions: 0 = every launch through k_conv; 1 (default) = the large
- * launches of the 64 -> 64 and 128 -> 128 layers through the weight-sharing kernel (conv_ws.hip); 2 = those layers'
- * launches of every size (tests).  Same results bit for bit.  mode < 0: query only.  -> the previous setting.
+/* Measurement / A-B switch of the fp32 sparse convolutions: 0 (default) = every launch through k_conv; 1 = the large
+ * launches of the 64 -> 64 and 128 -> 128 layers through the weight-sharing kernel (conv_ws.hip, measured slower); 2 =
+ * those layers' launches of every size (tests).  Same results bit for bit.  mode < 0: query only.  -> the previous setting.
  * Environment: D3D_CONV_WS.                                                                                          */
 int d3d_conv_ws_mode(int mode);
 /* ... and whether k_conv requests the next step's gathered rows behind the step's first MFMAs (1, default) or ahead of its

@@ -470,3 +470,35 @@ def test_geometry_chain_on_the_library_thread_equals_the_calls_made_in_line(dev)
     finally:
         main.wait_stream(geo)
         md.set_geometry_stream(None)
+
+
+def test_conv_variants_are_bit_identical(dev):
+    """The measured variants of the fp32 convolution produce the same bits as k_conv's default form: gathers requested ahead
+    of a step's matrix work (d3d_conv_late_mode 0) and the weight-sharing kernel of conv_ws.hip (d3d_conv_ws_mode 2: every
+    64 -> 64 / 128 -> 128 launch) -- with the fused BatchNorm prologue, the residual and the statistics epilogue."""
+    from detection_3d_amd import sparseconvnet as scn
+    from detection_3d_amd._lib import lib
+    size = (128, 128, 32)
+    _, coords, _ = small_scene(21, 40000, (2.5, 2.5, 0.6), size)
+    rng = np.random.RandomState(5)
+    for c in (64, 128):
+        feats = rng.randn(coords.shape[0], c).astype(np.float32)
+        outs = []
+        for late, ws in ((1, 0), (0, 0), (1, 2)):
+            lib().d3d_conv_late_mode(late)
+            lib().d3d_conv_ws_mode(ws)
+            try:
+                with torch.no_grad():
+                    t = scn.InputLayer(3, size, mode=4)([torch.from_numpy(coords), torch.from_numpy(feats).to(dev)])
+                    torch.manual_seed(c)
+                    bn = scn.BatchNormLeakyReLU(c, momentum=0.95, leakiness=0, track_running_stats=False).to(dev).eval()
+                    conv = scn.SubmanifoldConvolution(3, c, c, 3, False).to(dev)
+                    y = conv(bn(t), residual=t)
+                    y2 = conv(y)
+                    outs.append((y.features.clone(), y2.features.clone()))
+            finally:
+                lib().d3d_conv_late_mode(1)
+                lib().d3d_conv_ws_mode(0)
+        assert outs[0][0].abs().sum() > 0
+        for o in outs[1:]:
+            assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]), c
