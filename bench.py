@@ -49,13 +49,16 @@ def parse():
     ap.add_argument("--bf16-points", type=int, default=1_000_000)
     ap.add_argument("--bf16-batch", type=int, default=4)
     ap.add_argument("--bf16-steps", type=int, default=5)
+    ap.add_argument("--bf16-only", action="store_true",
+                    help="run only the `bf16_bs4` region and print its object (profiling runs of that region alone)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-points", type=int, default=500_000)
     return ap.parse_args()
 
 
-def pmc_traffic(template):
-    """-> (HBM-side bytes per launch of `template` or None, provenance string).  The PMC counters cannot be read from
+def pmc_traffic(template, section=None, source="conv.hip"):
+    """-> (HBM-side bytes per launch of `template` or None, provenance string).  `section`: sub-object of
+    profiles/pmc_current.json holding the passes of another kernel file (`source`, e.g. the bf16 region's).  The PMC counters cannot be read from
     inside the benchmark process, so the figure is replayed from the committed passes named by profiles/pmc_current.json
     (`rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` of this script, summed per kernel name by
     scripts/pmc_summary.py, in KB) -- but only while csrc/conv.hip still has the SHA-256 it had when they were taken;
@@ -67,10 +70,15 @@ def pmc_traffic(template):
         return None, "no profiles/pmc_current.json"
     with open(meta_path) as f:
         meta = json.load(f)
-    with open(os.path.join(ROOT, "detection_3d_amd", "csrc", "conv.hip"), "rb") as f:
+    if section is not None:
+        meta = meta.get(section)
+        if not meta:
+            return None, f"no '{section}' passes in profiles/pmc_current.json"
+    with open(os.path.join(ROOT, "detection_3d_amd", "csrc", source), "rb") as f:
         sha = hashlib.sha256(f.read()).hexdigest()
-    if sha != meta.get("conv_hip_sha256"):
-        return None, f"stale: {meta.get('fetch_csv')} was taken for another csrc/conv.hip ({str(meta.get('conv_hip_sha256'))[:12]})"
+    want = meta.get("sha256", meta.get("conv_hip_sha256"))
+    if sha != want:
+        return None, f"stale: {meta.get('fetch_csv')} was taken for another csrc/{source} ({str(want)[:12]})"
     tot = 0.0
     for name, factor in ((meta["fetch_csv"], 2.0), (meta["write_csv"], 1.0)):
         path = os.path.join(ROOT, "profiles", name)
@@ -86,7 +94,7 @@ def pmc_traffic(template):
             return None, f"kernel {template} not in profiles/{name}"
         tot += hit
     return tot, (f"bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE of profiles/{meta['fetch_csv']} / {meta['write_csv']} "
-                 f"(separate --pmc passes, taken at {meta.get('taken_at', '?')}, conv.hip {sha[:12]})")
+                 f"(separate --pmc passes, taken at {meta.get('taken_at', '?')}, {source} {sha[:12]})")
 
 
 def kernel_name(key):
@@ -94,8 +102,10 @@ def kernel_name(key):
     cin, cout = key
     cp = next(c for c in (16, 32, 64, 128, 256) if cin <= c)
     ct, nct = min(cp, 128), max(cp // 128, 1)
-    return (f"d3d::k_conv<{ct}, {nct}, {cout}, 1, {4 if cout == 32 else 1}, {'true' if cin == cp else 'false'}> "
-            f"(Cin={cin}, Cout={cout}, all filter volumes)")
+    vec = cin == cp
+    late = vec and ct >= 32        # launch_t: the late-gather form for 16-byte row pieces and Cin tiles of >= 32 channels
+    return (f"d3d::k_conv<{ct}, {nct}, {cout}, 1, {4 if cout == 32 else 1}, {'true' if vec else 'false'}, "
+            f"{'true' if late else 'false'}> (Cin={cin}, Cout={cout}, all filter volumes)")
 
 
 CPU_BASELINE_BUILDINGS = 3   # bounded sample: ~13 s of wall time on 16 threads
@@ -183,8 +193,11 @@ def bf16_region(args, cfg, model, dev, rank, world, barrier):
     if summ:
         key, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
         sec = d["ms"] * 1e-3
+        traffic, traffic_src = pmc_traffic(f"k_conv_bf16<{key[0] if key[0] <= 128 else 128}, {max(key[0] // 128, 1)}, {key[1]},",
+                                           section="bf16", source="conv_bf16.hip")
         out["roofline"] = {"bound": "hbm", "achieved": round(d["bytes"] / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(d["bytes"] / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                           "frac": round(d["bytes"] / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+                           "traffic_unit": traffic_src,
                            "kernel": f"d3d::k_conv_bf16 (Cin={key[0]}, Cout={key[1]})",
                            "launches_per_step": d["calls"] / steps, "avg_launch_us": round(d["ms"] / d["calls"] * 1e3, 1),
                            "tflops": round(d["flops"] / sec / 1e12, 1),
@@ -218,6 +231,20 @@ def main():
     # rank r owns scenes r, r + world, ... (seeds); resident in HBM before the timed region
     scenes = [torch.from_numpy(make_scene(rank + world * i, args.points)).to(dev) for i in range(args.scenes)]
 
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.bf16_only:
+        out = bf16_region(args, cfg, model, dev, rank, world, barrier)
+        if rank == 0:
+            print(json.dumps({"bf16_bs4": out}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     prof = SCN.ConvProfiler()
 
     def step(i, learn=False):
@@ -225,11 +252,6 @@ def main():
         prof.start_scene(i % len(scenes), learn)
         coords, feats = voxelize(pcl, cfg.SPARSE3D.VOXEL_SCALE, cfg.SPARSE3D.VOXEL_FULL_SCALE)
         return model([coords, feats])
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     # set-up pass (untimed, not a warm-up step): learn the rule count of every conv call of every
     # distinct scene, so that the timed region only records events (no extra synchronisation)

@@ -37,6 +37,22 @@ for p in $PASSES; do
         -- python3 $BENCH_SHORT > "$OUT/mfma.log" 2>&1
       python3 $REPO/scripts/pmc_multi.py "$OUT/mfma" "$OUT/pmc_mfma.csv" SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
       ;;
+    bf16trace)   # the bf16_bs4 region alone (BASELINE configs[4]: 4 x 1 M points, bf16 storage)
+      rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bf16trace" -- python3 $REPO/bench.py --bf16-only --bf16-steps 5 \
+        > "$OUT/bf16trace.log" 2>&1
+      cp "$(find "$OUT/bf16trace" -name '*kernel_stats.csv' | head -1)" "$OUT/bf16_kernel_stats.csv"
+      python3 $REPO/scripts/prof_summary.py "$OUT/bf16trace" 7 30 > "$OUT/bf16_kernel_stats.txt"
+      ;;
+    bf16fetch)
+      rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/bf16fetch" -- python3 $REPO/bench.py --bf16-only --bf16-steps 2 \
+        > "$OUT/bf16fetch.log" 2>&1
+      python3 $REPO/scripts/pmc_summary.py "$OUT/bf16fetch" FETCH_SIZE "$OUT/bf16_pmc_fetch.csv"
+      ;;
+    bf16write)
+      rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/bf16write" -- python3 $REPO/bench.py --bf16-only --bf16-steps 2 \
+        > "$OUT/bf16write.log" 2>&1
+      python3 $REPO/scripts/pmc_summary.py "$OUT/bf16write" WRITE_SIZE "$OUT/bf16_pmc_write.csv"
+      ;;
     inst)
       rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d "$OUT/inst" \
         -- python3 $BENCH_SHORT > "$OUT/inst.log" 2>&1
@@ -50,7 +66,12 @@ python3 - "$OUT" "$REPO" "$TAG" <<'EOF'
 import hashlib, json, os, sys, time
 out, repo, tag = sys.argv[1:4]
 sha = hashlib.sha256(open(os.path.join(repo, "detection_3d_amd/csrc/conv.hip"), "rb").read()).hexdigest()
-json.dump({"conv_hip_sha256": sha, "fetch_csv": f"{tag}_pmc_fetch.csv", "write_csv": f"{tag}_pmc_write.csv",
-           "taken_at": time.strftime("%Y-%m-%d %H:%M:%S")}, open(os.path.join(out, "pmc_current.json"), "w"), indent=1)
+meta = {"conv_hip_sha256": sha, "fetch_csv": f"{tag}_pmc_fetch.csv", "write_csv": f"{tag}_pmc_write.csv",
+        "taken_at": time.strftime("%Y-%m-%d %H:%M:%S")}
+if os.path.exists(os.path.join(out, "bf16_pmc_fetch.csv")) and os.path.exists(os.path.join(out, "bf16_pmc_write.csv")):
+    sha16 = hashlib.sha256(open(os.path.join(repo, "detection_3d_amd/csrc/conv_bf16.hip"), "rb").read()).hexdigest()
+    meta["bf16"] = {"sha256": sha16, "fetch_csv": f"{tag}_bf16_pmc_fetch.csv", "write_csv": f"{tag}_bf16_pmc_write.csv",
+                    "taken_at": meta["taken_at"]}
+json.dump(meta, open(os.path.join(out, "pmc_current.json"), "w"), indent=1)
 EOF
 ls -la "$OUT"
