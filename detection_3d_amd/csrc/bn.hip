@@ -344,10 +344,15 @@ static int run_stats_partials(const double *src, int src_rows, int rows, int C, 
   D3D_REQUIRE(C > 0 && C <= 4096 && C % 4 == 0, "batch norm: planes=%d must be a multiple of 4, <= 4096", C);
   D3D_REQUIRE(scratch && scratch_bytes >= d3d_bn_scratch_bytes(C), "batch norm: scratch too small");
   const int V = 2 * C, VP = V < kStatThreads ? V : kStatThreads, SL = kStatThreads / VP;
-  // >= 8 passes of the row lanes per workgroup and at most one first-level group of slices: the vectors are 0.1-12 MB
-  // per launch, and with a single ticket level the 30 finishes of a building take 0.1 ms less than with 128 slices
+  // >= 8 passes of the row lanes per workgroup and at most 64 slices (four first-level groups): the vectors are
+  // 0.1-12 MB per launch.  Measured on the 500 k-point building (30 finishes): 16 slices 4.78 ms per building, 64
+  // slices 4.75, 128 slices 4.76 (D3D_BN_SLICES).
   int nblk = (src_rows + 8 * SL - 1) / (8 * SL);
-  nblk = std::max(1, std::min(nblk, kStatGroup));
+  static const int max_slices = [] {
+    const char *e = getenv("D3D_BN_SLICES");
+    return e ? atoi(e) : 64;
+  }();
+  nblk = std::max(1, std::min(nblk, std::min(max_slices, kStatBlocks)));
   double *partial = (double *)((char *)scratch + kTicketBytes);
   double *gpartial = partial + (size_t)kStatBlocks * 2 * C;
   double *total = gpartial + (size_t)kStatMaxGroups * 2 * C;
