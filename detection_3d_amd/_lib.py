@@ -6,7 +6,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libd3d_hip.so")
+LIB_PATH = os.environ.get("D3D_LIB_PATH") or os.path.join(_HERE, "lib", "libd3d_hip.so")   # (the override: A/B runs of library builds)
 
 _lib = None
 
@@ -169,6 +169,7 @@ _SIGS = {
                                                   vp, vp, vp, ctypes.c_size_t, vp]),
     "d3d_bn_batch_invstd_dt": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, vp, vp, vp,
                                               ctypes.c_size_t, ctypes.c_int, vp]),
+    "d3d_rows_to_bf16": (ctypes.c_int, [vp, ctypes.c_long, ctypes.c_int, ctypes.c_int, vp, vp]),
     "d3d_bn_apply_dt": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_float,
                                        ctypes.c_int, vp]),
 }

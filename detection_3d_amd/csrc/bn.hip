@@ -10,6 +10,8 @@ static constexpr int kStatThreads = 1024;
 static constexpr int kStatBlocks = 128;   // row slices: every workgroup pays an agent-scope release / acquire (an L2
                                           // write-back on this multi-XCD part) and its partials a reduction pass --
                                           // measured per building: 512 slices 0.60 ms, 256 0.53, 128 0.49, 64 0.53
+                                          // (1024 slices for the 180 MB maps of a 4 x 1 M-point bf16 batch: no change --
+                                          // those passes run beside the rulebooks' hash probes, which hold the HBM)
 static constexpr int kStatGroup = 16;     // slices per first-level group
 static constexpr int kStatMaxGroups = kStatBlocks / kStatGroup;
 static constexpr size_t kTicketBytes = 256;  // [0] = groups done, [1 + g] = slices of group g done
@@ -362,6 +364,23 @@ static int run_stats_partials(const double *src, int src_rows, int rows, int C, 
   return D3D_OK;
 }
 
+// fp32 rows [rows, cin] -> bf16 rows [rows, width] (width >= cin a multiple of 8; the channels past cin are zero): the
+// input layer's per-voxel means as the bf16 backbone stores them.  One thread per 8 output channels (one 16-byte store).
+__global__ __launch_bounds__(256) void k_rows_to_bf16(const float *__restrict__ in, long rows, int cin, int width,
+                                                      unsigned short *__restrict__ out) {
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  const int g8 = width / 8;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * g8) return;
+  const long row = t / g8;
+  const int c0 = (int)(t - row * g8) * 8;
+  const float *p = in + row * cin;
+  bf16x8 b;
+#pragma unroll
+  for (int j = 0; j < 8; j++) b[j] = (__bf16)(c0 + j < cin ? p[c0 + j] : 0.f);   // round to nearest even, as torch's .to()
+  *(uint4 *)(out + row * width + c0) = __builtin_bit_cast(uint4, b);
+}
+
 }  // namespace d3d
 
 using namespace d3d;
@@ -448,6 +467,18 @@ int d3d_bn_apply_dt(const void *in, void *out, int rows, int planes, const float
   const unsigned blocks = (unsigned)std::max<long>(1, std::min<long>(need, 256 * 8));
   hipLaunchKernelGGL(k_bn_apply_rows<unsigned short>, dim3(blocks), dim3(256), 0, s, (const unsigned short *)in,
                      (unsigned short *)out, rows, planes, mean, invstd, weight, bias, leakiness);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+int d3d_rows_to_bf16(const float *in, long rows, int cin, int width, void *out, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(rows >= 0 && cin > 0 && width >= cin && width % 8 == 0, "rows_to_bf16: bad arguments (cin=%d, width=%d)", cin, width);
+  if (rows == 0) return D3D_OK;
+  D3D_REQUIRE(in && out && ((uintptr_t)out & 15) == 0, "rows_to_bf16: null or unaligned pointer");
+  const long total = rows * (width / 8);
+  hipLaunchKernelGGL(k_rows_to_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, rows, cin, width,
+                     (unsigned short *)out);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }

@@ -83,7 +83,12 @@ __global__ __launch_bounds__(BPW *(COUT / 32 / NT) * 64) void k_conv(
   constexpr int RPP = TPB / LPR;   // rows per gather pass
   constexpr int NIT = (32 / RPP) > 0 ? (32 / RPP) : 1;
   constexpr int NQ = CT / 8;       // q-iterations (4 MFMAs per accumulator tile each) of a step
-  constexpr int QA = NQ < 4 ? NQ : 4;  // weight fragments in flight (ring)
+  // weight fragments in flight (ring): 8 q-iterations = 2048 matrix cycles of lead (4: the 128 -> 128 family 0.91 ms per
+  // building against 0.89, 2: 0.95; D3D_QA at compile time)
+#ifndef D3D_QA
+#define D3D_QA 8
+#endif
+  constexpr int QA = NQ < D3D_QA ? NQ : D3D_QA;
   static_assert(NQ % QA == 0, "ring depth must divide the q-iterations of a step");
   __shared__ __attribute__((aligned(16))) float smem[BPW * 32 * LDA];
 

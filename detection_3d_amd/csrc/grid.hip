@@ -75,15 +75,18 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_tiles(const int32_t *__re
   if (tid == kScanThreads - 1) tile_sums[blockIdx.x] = run;
 }
 
-__global__ __launch_bounds__(1024) void k_scan_sums(int32_t *__restrict__ sums, int nb,
-                                                    int32_t *__restrict__ total) {
+// (one workgroup of 4 waves: it finds a free slot beside the convolutions of another stream at once -- as 16 waves it
+//  waited ~0.1 ms per call for a CU to drain in the 4 x 1 M-point step)
+static constexpr int kSumThreads = 256;
+__global__ __launch_bounds__(kSumThreads) void k_scan_sums(int32_t *__restrict__ sums, int nb,
+                                                           int32_t *__restrict__ total) {
   D3D_SIDE_PRIO();
-  __shared__ int wave_tot[16];
+  __shared__ int wave_tot[kSumThreads / 64];
   __shared__ int carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) carry_s = 0;
   __syncthreads();
-  for (int base = 0; base < nb; base += 1024) {
+  for (int base = 0; base < nb; base += kSumThreads) {
     int i = base + tid;
     int v = i < nb ? sums[i] : 0;
     int incl = wave_inclusive_scan(v, lane);
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(1024) void k_scan_sums(int32_t *__restrict__ sums, 
     for (int w = 0; w < wave; w++) off += wave_tot[w];
     if (i < nb) sums[i] = off + incl - v;
     __syncthreads();
-    if (tid == 1023) carry_s = off + incl;
+    if (tid == kSumThreads - 1) carry_s = off + incl;
     __syncthreads();
   }
   if (tid == 0 && total) *total = carry_s;
@@ -118,7 +121,7 @@ int scan_exclusive_i32(const int32_t *in, int32_t *out, int n, int32_t *total_de
   int nb = (n + kScanTile - 1) / kScanTile;
   D3D_ALLOC(sums, int32_t, scratch, nb);
   hipLaunchKernelGGL(k_scan_tiles, dim3(nb), dim3(kScanThreads), 0, s, in, out, n, sums);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, sums, nb, total_dev);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kSumThreads), 0, s, sums, nb, total_dev);
   hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(kScanThreads), 0, s, out, n, sums);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
@@ -650,17 +653,18 @@ __global__ void k_store_counts(CountPtrs c, int32_t *__restrict__ host) {
 // Threads keep their entries' slots in registers; table fields other threads wrote are read with agent-scope atomic
 // loads (L2), never through a possibly stale L1 line.
 static constexpr int kSmallGrid = 4096;                        // entries one workgroup takes (16 k: slower than the 11 launches)
-static constexpr int kSmallGridEPT = kSmallGrid / 1024;
+static constexpr int kSmallGridThreads = 256;                  // 4 waves: finds a slot on a busy CU (see k_plan_small)
+static constexpr int kSmallGridEPT = kSmallGrid / kSmallGridThreads;
 // n_in_dev (may be null): the input site count on the device (n_entries / n_in are then upper bounds; the grid chain);
 // prefilled: table and rulebook arrays already hold 0xFF (the chain's one fill launch); nbr_dec may be null.
-__global__ __launch_bounds__(1024) void k_conv_grid_small(const int32_t *__restrict__ loc, int n_entries, ConvGeom g,
+__global__ __launch_bounds__(kSmallGridThreads) void k_conv_grid_small(const int32_t *__restrict__ loc, int n_entries, ConvGeom g,
                                                           int K, int n_in, HashEntry *tab, int cap,
                                                           int32_t *__restrict__ loc_out, int32_t *__restrict__ nbr_fwd,
                                                           int32_t *__restrict__ nbr_dec, int32_t *__restrict__ total,
                                                           const int32_t *__restrict__ n_in_dev, int prefilled) {
   D3D_SIDE_PRIO();
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  __shared__ int wsum[16];
+  __shared__ int wsum[kSmallGridThreads / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (n_in_dev) {
     n_in = *n_in_dev;
@@ -668,10 +672,10 @@ __global__ __launch_bounds__(1024) void k_conv_grid_small(const int32_t *__restr
   }
   if (!prefilled) {
     const u32x4 ones = {~0u, ~0u, ~0u, ~0u};
-    for (int i = tid; i < cap; i += 1024) *(u32x4 *)&tab[i] = ones;
+    for (int i = tid; i < cap; i += kSmallGridThreads) *(u32x4 *)&tab[i] = ones;
     if (nbr_dec)
-      for (int i = tid; i < n_in * K + 1; i += 1024) nbr_dec[i] = -1;
-    for (int i = tid; i < n_entries * K + 1; i += 1024) nbr_fwd[i] = -1;      // n_out <= n_entries rows are read later
+      for (int i = tid; i < n_in * K + 1; i += kSmallGridThreads) nbr_dec[i] = -1;
+    for (int i = tid; i < n_entries * K + 1; i += kSmallGridThreads) nbr_fwd[i] = -1;      // n_out <= n_entries rows are read later
     __syncthreads();   // every wave's stores have reached L2 ...
     if (tid == 0) __threadfence();   // ... one agent-scope fence for the workgroup (as in k_bn_stats)
     __syncthreads();
@@ -679,7 +683,7 @@ __global__ __launch_bounds__(1024) void k_conv_grid_small(const int32_t *__restr
   int slot_r[kSmallGridEPT];
 #pragma unroll
   for (int it = 0; it < kSmallGridEPT; it++) {
-    const int e = it * 1024 + tid;
+    const int e = it * kSmallGridThreads + tid;
     int slot = -1;
     if (e < n_entries) {
       const int32_t *p = loc + (size_t)(e / g.max_out) * 4;
@@ -697,8 +701,8 @@ __global__ __launch_bounds__(1024) void k_conv_grid_small(const int32_t *__restr
   int base = 0;
 #pragma unroll
   for (int it = 0; it < kSmallGridEPT; it++) {
-    if (it * 1024 >= n_entries) break;                                       // block-uniform
-    const int e = it * 1024 + tid, slot = slot_r[it];
+    if (it * kSmallGridThreads >= n_entries) break;                                       // block-uniform
+    const int e = it * kSmallGridThreads + tid, slot = slot_r[it];
     const bool first = slot >= 0 &&
                        __hip_atomic_load(&tab[slot].first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)e;
     const unsigned long long bal = __ballot(first);
@@ -706,7 +710,7 @@ __global__ __launch_bounds__(1024) void k_conv_grid_small(const int32_t *__restr
     __syncthreads();
     int before = 0, all = 0;
 #pragma unroll
-    for (int w = 0; w < 16; w++) {
+    for (int w = 0; w < kSmallGridThreads / 64; w++) {
       const int c = wsum[w];
       before += w < wave ? c : 0;
       all += c;
@@ -731,7 +735,7 @@ __global__ __launch_bounds__(1024) void k_conv_grid_small(const int32_t *__restr
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < kSmallGridEPT; it++) {
-    const int e = it * 1024 + tid, slot = slot_r[it];
+    const int e = it * kSmallGridThreads + tid, slot = slot_r[it];
     if (slot < 0) continue;
     const int i = e / g.max_out;
     const int32_t *p = loc + (size_t)i * 4;
@@ -947,7 +951,8 @@ __global__ __launch_bounds__(256) void k_plan_finish(const int32_t *__restrict__
 // key16 = (K - popcount) << 11 | (mask if K <= 11 else an 11-bit hash of it): heaviest rows first, equal masks
 // adjacent (hash collisions only cost a little padding).
 static constexpr int kSmallMax = 8192;  // (16384 rows / 512 threads measured slower than the rocPRIM path)
-static constexpr int kSmallThreads = 1024;
+static constexpr int kSmallThreads = 256;   // 4 waves and 72 KB of LDS: fits beside the convolutions' workgroups on a busy CU (as 16
+                                            // waves + 96 KB it waited up to 0.15 ms per call for a CU to drain)
 __global__ __launch_bounds__(kSmallThreads) void k_plan_small(const int32_t *__restrict__ nbr,
                                                               const uint32_t *__restrict__ mask_in, int n_rows,
                                                               int K, int32_t *__restrict__ rows) {
@@ -958,14 +963,29 @@ __global__ __launch_bounds__(kSmallThreads) void k_plan_small(const int32_t *__r
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (n_rows + kSmallThreads - 1) / kSmallThreads;
   const int i0 = min(n_rows, tid * per), i1 = min(n_rows, i0 + per);
-  for (int i = i0; i < i1; i++) {
-    uint32_t m;
-    if (mask_in)
-      m = plan_key_mask(mask_in[i], K);
-    else {
-      m = 0;
-      for (int k = 0; k < K; k++) m |= (nbr[(size_t)i * K + k] >= 0 ? 1u : 0u) << k;
+  if (!mask_in) {
+    // masks from the table itself: the workgroup walks it front to back (coalesced, independent loads), bits OR-ed
+    // into buf[1]
+    for (int i = tid; i < n_rows; i += kSmallThreads) buf[1][i] = 0;
+    __syncthreads();
+    const int total = n_rows * K;
+    for (int e0 = 0; e0 < total; e0 += 8 * kSmallThreads) {
+      int v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int e = e0 + u * kSmallThreads + tid;
+        v[u] = e < total ? nbr[e] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int e = e0 + u * kSmallThreads + tid;
+        if (v[u] >= 0) atomicOr(&buf[1][e / K], 1u << (e % K));
+      }
     }
+    __syncthreads();
+  }
+  for (int i = i0; i < i1; i++) {
+    const uint32_t m = mask_in ? plan_key_mask(mask_in[i], K) : buf[1][i];
     const uint32_t lo = K <= 11 ? m : (m * 0x9E3779B1u) >> 21;
     buf[0][i] = ((((uint32_t)(K - __popc(m)) << 11) | lo) << 16) | (uint32_t)i;
   }
@@ -2138,7 +2158,7 @@ int d3d_conv_prepare(d3d_meta *m, const int *in_size, const int *out_size, const
       CapGuard guard(A, (A.cap - raw_bytes) & ~size_t(255));
       size_t mark = A.used;
       D3D_ALLOC(total, int32_t, A, 1);
-      hipLaunchKernelGGL(k_conv_grid_small, dim3(1), dim3(1024), 0, s, gi->loc, (int)n_entries, geo, K, n_in, tab, go.cap,
+      hipLaunchKernelGGL(k_conv_grid_small, dim3(1), dim3(kSmallGridThreads), 0, s, gi->loc, (int)n_entries, geo, K, n_in, tab, go.cap,
                          loc_out, nbr_fwd, nbr_dec, total, (const int32_t *)nullptr, 0);
       D3D_LAUNCH_CHECK();
       D3D_HIP_CHECK(hipMemcpyAsync(&m->host_words[1], total, sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -2384,7 +2404,7 @@ static int run_grid_chain(d3d_meta *m, const std::vector<ChainSpec> &specs, hipS
       continue;
     }
     if (v.small) {
-      hipLaunchKernelGGL(k_conv_grid_small, dim3(1), dim3(1024), 0, s, v.loc_in, (int)v.bound_entries, v.geo, v.K,
+      hipLaunchKernelGGL(k_conv_grid_small, dim3(1), dim3(kSmallGridThreads), 0, s, v.loc_in, (int)v.bound_entries, v.geo, v.K,
                          (int)v.bound_in, v.go.tab, v.go.cap, v.go.loc, v.nbr_fwd, v.nbr_dec, v.n_out_dev, v.n_in_dev, 1);
       continue;
     }

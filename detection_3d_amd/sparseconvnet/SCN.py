@@ -303,6 +303,15 @@ def stored_planes(planes, dtype):
     return planes
 
 
+def rows_to_bf16(features, width):
+    """fp32 [n, c] -> bf16 [n, width] rows, zero padded (d3d_rows_to_bf16): F.pad + .to(bfloat16) in one launch"""
+    require_gpu(features)
+    f = features.contiguous()
+    out = torch.empty((f.shape[0], width), dtype=torch.bfloat16, device=f.device)
+    check(lib().d3d_rows_to_bf16(ptr(f), f.shape[0], f.shape[1], int(width), ptr(out), stream_of()))
+    return out
+
+
 def n_rulebook_bits():
     return 32
 
@@ -374,15 +383,17 @@ def InputLayer_updateOutput(m, spatial_size, input_coords, input_features, outpu
 
     def run_forward(on=None):
         """the input layer's feature pass (d3d_input_layer_forward), on stream `on` (a torch stream) or the current one;
-        the hook may call it where it suits its streams -- e.g. right behind the point lists on a side stream"""
+        the hook may call it where it suits its streams -- e.g. right behind the point lists on a side stream.
+        -> the tensor being filled (None when the pass was already enqueued)"""
         if done:
-            return
+            return None
         done.append(True)
         if on is None:
             check(lib().d3d_input_layer_forward(m._h, ptr(feats), planes, ptr(output_features), stream_of()))
         else:
             with torch.cuda.stream(on):
                 check(lib().d3d_input_layer_forward(m._h, ptr(feats), planes, ptr(output_features), stream_of()))
+        return output_features
 
     hook = getattr(_TLS, "after_input_build", None)
     if hook is not None:

@@ -269,6 +269,11 @@ int d3d_bn_batch_invstd_dt(const void *in, int rows, int planes, float eps, floa
                            void *scratch, size_t scratch_bytes, int dtype, void *stream);
 int d3d_bn_apply_dt(const void *in, void *out, int rows, int planes, const float *mean, const float *invstd,
                     const float *weight, const float *bias, float leakiness, int dtype, void *stream);
+/* fp32 rows [rows, cin] -> bf16 rows [rows, width], width >= cin a multiple of 8, the channels past cin zero, round to
+ * nearest even: the input layer's output as the bf16 backbone stores it (fpn_net.py:150 hands the fp32 means to the first
+ * convolution; the bf16 storage of BASELINE configs[4] pads the 9 input channels to 16).  One launch instead of a pad and a
+ * cast.                                                                                                             */
+int d3d_rows_to_bf16(const float *in, long rows, int cin, int width, void *out, void *stream);
 
 /* a7. Backward (training).  SubmanifoldConvolution_backward / Convolution_backward / Deconvolution_backward
  * (SCN/sparseconvnet.h:92-98,106-111,153-158; SCN/CUDA/Convolution.cu:249-442): d_in is overwritten,

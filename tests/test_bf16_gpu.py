@@ -164,3 +164,20 @@ def test_backbone_bf16_vs_oracle_and_fp32(dev):
         assert rel_err(g16, wf) < 5e-2, rel_err(g16, wf)
         assert rel_err(g16, g32) < 5e-2
         assert rel_err(g32, wf) < 2e-4
+
+
+@pytest.mark.parametrize("n,c,width", [(1, 9, 16), (1000, 9, 16), (4097, 3, 16), (777, 32, 32), (50, 20, 32), (0, 9, 16)])
+def test_rows_to_bf16_is_pad_and_cast(dev, n, c, width):
+    """d3d_rows_to_bf16 == F.pad(x, (0, width - c)).to(bfloat16) bit for bit (round to nearest even, channels past c zero,
+    NaN / Inf kept): the hand-over of the input layer's fp32 means to the bf16 backbone."""
+    from detection_3d_amd.sparseconvnet import SCN
+    g = torch.Generator().manual_seed(n + c)
+    x = (torch.randn(n, c, generator=g) * 100).to(dev)
+    if n > 3:
+        x[0, 0], x[1, 1], x[2, 2] = float("inf"), float("-inf"), 1.0 + 2.0 ** -9     # (a tie of the rounding)
+        x[3, 0] = float("nan")
+    got = SCN.rows_to_bf16(x, width)
+    want = torch.nn.functional.pad(x, (0, width - c)).to(torch.bfloat16)
+    assert got.shape == want.shape and got.dtype == torch.bfloat16
+    assert torch.equal(got.view(torch.int16)[~torch.isnan(want)], want.view(torch.int16)[~torch.isnan(want)])
+    assert torch.equal(torch.isnan(got), torch.isnan(want))
