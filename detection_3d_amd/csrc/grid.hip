@@ -951,8 +951,7 @@ __global__ __launch_bounds__(256) void k_plan_finish(const int32_t *__restrict__
 // key16 = (K - popcount) << 11 | (mask if K <= 11 else an 11-bit hash of it): heaviest rows first, equal masks
 // adjacent (hash collisions only cost a little padding).
 static constexpr int kSmallMax = 8192;  // (16384 rows / 512 threads measured slower than the rocPRIM path)
-static constexpr int kSmallThreads = 256;   // 4 waves and 72 KB of LDS: fits beside the convolutions' workgroups on a busy CU (as 16
-                                            // waves + 96 KB it waited up to 0.15 ms per call for a CU to drain)
+static constexpr int kSmallThreads = 1024;
 __global__ __launch_bounds__(kSmallThreads) void k_plan_small(const int32_t *__restrict__ nbr,
                                                               const uint32_t *__restrict__ mask_in, int n_rows,
                                                               int K, int32_t *__restrict__ rows) {
@@ -963,29 +962,14 @@ __global__ __launch_bounds__(kSmallThreads) void k_plan_small(const int32_t *__r
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (n_rows + kSmallThreads - 1) / kSmallThreads;
   const int i0 = min(n_rows, tid * per), i1 = min(n_rows, i0 + per);
-  if (!mask_in) {
-    // masks from the table itself: the workgroup walks it front to back (coalesced, independent loads), bits OR-ed
-    // into buf[1]
-    for (int i = tid; i < n_rows; i += kSmallThreads) buf[1][i] = 0;
-    __syncthreads();
-    const int total = n_rows * K;
-    for (int e0 = 0; e0 < total; e0 += 8 * kSmallThreads) {
-      int v[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int e = e0 + u * kSmallThreads + tid;
-        v[u] = e < total ? nbr[e] : -1;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int e = e0 + u * kSmallThreads + tid;
-        if (v[u] >= 0) atomicOr(&buf[1][e / K], 1u << (e % K));
-      }
-    }
-    __syncthreads();
-  }
   for (int i = i0; i < i1; i++) {
-    const uint32_t m = mask_in ? plan_key_mask(mask_in[i], K) : buf[1][i];
+    uint32_t m;
+    if (mask_in)
+      m = plan_key_mask(mask_in[i], K);
+    else {
+      m = 0;
+      for (int k = 0; k < K; k++) m |= (nbr[(size_t)i * K + k] >= 0 ? 1u : 0u) << k;
+    }
     const uint32_t lo = K <= 11 ? m : (m * 0x9E3779B1u) >> 21;
     buf[0][i] = ((((uint32_t)(K - __popc(m)) << 11) | lo) << 16) | (uint32_t)i;
   }
