@@ -27,7 +27,11 @@ ASYNC_VIEWS = os.environ.get("D3D_ASYNC_VIEWS", "1") != "0"         # ... and th
 SIDE_START = os.environ.get("D3D_SIDE_START", "scene")              # "main": side streams wait for the caller's stream at the
                     # input grid (and the point lists go to the geometry stream), as before the grid chain -- A/B runs
 _GEO_STREAMS = {}   # (device, caller's stream) -> side streams
-_SIDE_PRIORITY = int(os.environ.get("D3D_SIDE_PRIORITY", "-1"))     # -1: high (geometry ahead of the convolutions), 0: normal
+# priority of the side streams: 0 = normal (default), -1 = high (geometry ahead of the convolutions).  Measured in pairs on
+# two boxes: 4.80 (high) against 4.82 ms (normal) per building on one, 5.28-5.37 against 4.86-4.95 on the other -- high
+# priority buys nothing where it works and costs 8 % where the queue scheduler lets the geometry kernels hold back the
+# caller's stream
+_SIDE_PRIORITY = int(os.environ.get("D3D_SIDE_PRIORITY", "0"))
 
 
 def _is_gpu_input(net0):
