@@ -143,6 +143,7 @@ _SIGS = {
                                         ctypes.POINTER(ctypes.c_float), ctypes.c_float, vp, vp]),
     "d3d_rpn_head": (ctypes.c_int, [ctypes.POINTER(vp), c_int_p, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp,
                                     ctypes.c_int, vp, vp, vp]),
+    "d3d_mlp_heads": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int, vp, vp, vp]),
     "d3d_rotate_nms_3d_sorted": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, vp, vp, vp,
                                                 ctypes.c_size_t, vp]),
     "d3d_nms_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int]),

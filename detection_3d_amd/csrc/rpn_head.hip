@@ -9,6 +9,8 @@
 // accumulator of columns 32w.. of t (v_mfma_f32_32x32x2_f32 over Cin, A from the LDS tile of the rows, B from the
 // k-interleaved packed weights as in k_conv); bias + ReLU; t replaces the rows in LDS.  Stage 2: the a objectness and
 // 7a regression columns are one packed [C, 8a] operand (32 columns for a = 4), a 32-column tile per wave.
+#include <algorithm>
+
 #include "d3d_internal.h"
 
 namespace d3d {
@@ -42,11 +44,16 @@ __device__ __forceinline__ f32x16 tile_product(const float *__restrict__ As, int
   return acc;
 }
 
-template <int C>
+// RELU_IN: the rows are rectified as they are loaded (the box head's fc6 output, roi_box_feature_extractors.py:110-115).
+// stages: bit 0 = stage 1 (t = relu(rows W1^T + b1), kept in LDS; written to t_out when that is not null), bit 1 = stage 2
+// (the two outputs from t); with stage 2 alone the rows ARE t.  Stage 2 reads the same fp32 values from LDS that stage 1
+// would have stored to t_out, so a fused launch and the two stages launched apart give the same bits.
+template <int C, bool RELU_IN>
 __global__ __launch_bounds__(C / 32 * 64) void k_rpn_head(RpnMaps maps, const float *__restrict__ w1p,
                                                           const float *__restrict__ b1, const float *__restrict__ w2p,
                                                           const float *__restrict__ b2, int a, int out_tiles,
-                                                          float *__restrict__ obj, float *__restrict__ reg) {
+                                                          float *__restrict__ obj, float *__restrict__ reg, int stages,
+                                                          float *__restrict__ t_out) {
   constexpr int W = C / 32, LDA = C + 4, LPR = C / 4;
   __shared__ __attribute__((aligned(16))) float As[32 * LDA];
   const int n = maps.start[maps.n_maps];
@@ -60,12 +67,16 @@ __global__ __launch_bounds__(C / 32 * 64) void k_rpn_head(RpnMaps maps, const fl
       int m = 0;
       while (m + 1 < maps.n_maps && g >= maps.start[m + 1]) m++;
       v = *(const f32x4 *)(maps.p[m] + (size_t)(g - maps.start[m]) * C + c4 * 4);
+      if constexpr (RELU_IN) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = v[j] < 0.f ? 0.f : v[j];   // relu; a NaN stays a NaN
+      }
     }
     *(f32x4 *)(As + row * LDA + c4 * 4) = v;
   }
   __syncthreads();
   // C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  {
+  if (stages & 1) {
     const f32x16 acc = tile_product<C>(As, LDA, w1p, C, wib * 32, r, h);
     const int col = wib * 32 + r;
     const float bias = b1[col];
@@ -73,11 +84,14 @@ __global__ __launch_bounds__(C / 32 * 64) void k_rpn_head(RpnMaps maps, const fl
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-      const float v = acc[i] + bias;
-      As[row * LDA + col] = v < 0.f ? 0.f : v;   // relu; a NaN stays a NaN
+      float v = acc[i] + bias;
+      v = v < 0.f ? 0.f : v;   // relu; a NaN stays a NaN
+      As[row * LDA + col] = v;
+      if (t_out && row0 + row < n) t_out[(size_t)(row0 + row) * C + col] = v;
     }
+    __syncthreads();
   }
-  __syncthreads();
+  if (!(stages & 2)) return;
   const int nout = out_tiles * 32;
   for (int t = wib; t < out_tiles; t += W) {
     const f32x16 acc = tile_product<C>(As, LDA, w2p, nout, t * 32, r, h);
@@ -131,11 +145,47 @@ int d3d_rpn_head(const float *const *maps_host, const int *rows_host, int n_maps
   const int out_tiles = (8 * a + 31) / 32;
   const dim3 grid((unsigned)((n + 31) / 32));
   if (channels == 128)
-    hipLaunchKernelGGL(k_rpn_head<128>, grid, dim3(256), 0, s, maps, w1_packed, b1, w2_packed, b2, a, out_tiles,
-                       objectness, regression);
+    hipLaunchKernelGGL((k_rpn_head<128, false>), grid, dim3(256), 0, s, maps, w1_packed, b1, w2_packed, b2, a, out_tiles,
+                       objectness, regression, 3, (float *)nullptr);
   else
-    hipLaunchKernelGGL(k_rpn_head<256>, grid, dim3(512), 0, s, maps, w1_packed, b1, w2_packed, b2, a, out_tiles,
-                       objectness, regression);
+    hipLaunchKernelGGL((k_rpn_head<256, false>), grid, dim3(512), 0, s, maps, w1_packed, b1, w2_packed, b2, a, out_tiles,
+                       objectness, regression, 3, (float *)nullptr);
+  D3D_LAUNCH_CHECK();
+  return D3D_OK;
+}
+
+int d3d_mlp_heads(const float *x, int rows, int channels, int relu_in, const float *w1_packed, const float *b1,
+                  float *t_out, const float *w2_packed, const float *b2, int a, float *out_a, float *out_7a, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D3D_REQUIRE(rows >= 0 && (channels == 128 || channels == 256 || channels == 512),
+              "mlp_heads: %d channels (built for 128, 256 and 512)", channels);
+  const int stages = (w1_packed ? 1 : 0) | (w2_packed ? 2 : 0);
+  D3D_REQUIRE(stages != 0 && (!w1_packed || b1) && (!w2_packed || (b2 && a >= 1 && out_a && out_7a)) &&
+                  (w2_packed || t_out), "mlp_heads: bad arguments");
+  D3D_REQUIRE(!(relu_in && !w1_packed), "mlp_heads: the input is only rectified in front of the first stage");
+  D3D_REQUIRE((long)rows * 7L * std::max(a, 1) < (1L << 31), "mlp_heads: %d rows", rows);
+  if (rows == 0) return D3D_OK;
+  D3D_REQUIRE(x, "mlp_heads: null input");
+  RpnMaps maps;
+  for (int m = 0; m < D3D_RPN_MAX_MAPS; m++) {
+    maps.p[m] = m == 0 ? x : nullptr;
+    maps.start[m] = m == 0 ? 0 : rows;
+  }
+  maps.start[D3D_RPN_MAX_MAPS] = rows;
+  maps.n_maps = 1;
+  const int out_tiles = w2_packed ? (8 * a + 31) / 32 : 0;
+  const dim3 grid((unsigned)((rows + 31) / 32));
+#define D3D_MLP_LAUNCH(CC, RI)                                                                                         \
+  hipLaunchKernelGGL((k_rpn_head<CC, RI>), grid, dim3(CC / 32 * 64), 0, s, maps, w1_packed, b1, w2_packed, b2, a, out_tiles, \
+                     out_a, out_7a, stages, t_out)
+  if (channels == 128) {
+    if (relu_in) D3D_MLP_LAUNCH(128, true); else D3D_MLP_LAUNCH(128, false);
+  } else if (channels == 256) {
+    if (relu_in) D3D_MLP_LAUNCH(256, true); else D3D_MLP_LAUNCH(256, false);
+  } else {
+    if (relu_in) D3D_MLP_LAUNCH(512, true); else D3D_MLP_LAUNCH(512, false);
+  }
+#undef D3D_MLP_LAUNCH
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }

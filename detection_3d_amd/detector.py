@@ -102,6 +102,7 @@ def build_backbone(cfg):
 
 _ANCHORS_ONE_LAUNCH = os.environ.get("D3D_ANCHOR_LAUNCHES", "one") != "per-map"
 _FUSED_RPN_HEAD = os.environ.get("D3D_RPN_HEAD", "fused") != "gemm"     # "gemm": the library-GEMM form, for A/B runs
+_FUSED_BOX_MLP = os.environ.get("D3D_BOX_MLP", "fused") != "gemm"       # ... of fc7 and the predictor behind fc6
 
 
 # ----------------------------------------------------------------------------------------------
@@ -498,6 +499,20 @@ class Pooler(nn.Module):
         return result
 
 
+def _pack_linear(w):
+    """nn.Linear weight [cout, c] -> the [c/4, cout, 4] operand of d3d_rpn_head / d3d_mlp_heads (rows padded to 32)"""
+    cout, c = w.shape
+    pad = (-cout) % 32
+    if pad:
+        w = torch.cat([w, w.new_zeros(pad, c)], 0)
+    return w.view(w.shape[0], c // 4, 4).permute(1, 0, 2).contiguous()
+
+
+def _mlp_rows_ok(x):
+    return (_FUSED_BOX_MLP and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+            and x.is_contiguous() and x.shape[1] in (128, 256, 512) and x.shape[0] > 0)
+
+
 class FPN2MLPFeatureExtractor(nn.Module):
     """roi_heads/box_head_3d/roi_box_feature_extractors.py:47-117."""
 
@@ -575,9 +590,37 @@ class FPN2MLPFeatureExtractor(nn.Module):
             run = self._bn_running = (y.new_zeros(rep), y.new_ones(rep))
         SCN.BatchNormalization_updateOutput(y, out, sm, si, run[0], run[1], bn.weight, bn.bias, bn.eps, 0.0, True, 0.0)
         h = torch.addmm(self.fc6.bias, out.view(K, ph * pw * rep), self._fc6_rows_weight(ph * pw).t())
-        h = F.relu(self.fc7(F.relu(h)))
+        h = self._fc7_and_heads(h)
         mark("box features")
         return h
+
+    def _fc7_packed(self):
+        w, b = self.fc7.weight, self.fc7.bias
+        key = (w.data_ptr(), w._version, b.data_ptr(), b._version)
+        if getattr(self, "_fc7_pack", (None,))[0] != key:
+            self._fc7_pack = (key, _pack_linear(w.detach()), b.detach().contiguous())
+        return self._fc7_pack[1:]
+
+    def _fc7_and_heads(self, h6):
+        """relu(fc7(relu(h6))) -- and, when the box head has handed its predictor over (`_heads`), cls_score and bbox_pred
+        of the result in the same launch (d3d_mlp_heads; they ride on the returned tensor for FPNPredictor.forward, which
+        produces the same bits when it is called on its own)."""
+        if not (_mlp_rows_ok(h6) and self.fc7.in_features == self.fc7.out_features == h6.shape[1]):
+            return F.relu(self.fc7(F.relu(h6)))
+        w1, b1 = self._fc7_packed()
+        x = torch.empty_like(h6)
+        pred = getattr(self, "_heads", None)
+        if pred is not None and pred.fusable(x):
+            w2, b2, a, key = pred.packed()
+            logits = torch.empty((x.shape[0], a), dtype=torch.float32, device=x.device)
+            reg = torch.empty((x.shape[0], 7 * a), dtype=torch.float32, device=x.device)
+            check(lib().d3d_mlp_heads(ptr(h6), x.shape[0], x.shape[1], 1, ptr(w1), ptr(b1), ptr(x), ptr(w2), ptr(b2), a,
+                                      ptr(logits), ptr(reg), stream_of()))
+            x._d3d_heads = (key, logits, reg)
+        else:
+            check(lib().d3d_mlp_heads(ptr(h6), x.shape[0], x.shape[1], 1, ptr(w1), ptr(b1), ptr(x), None, None, 0, None,
+                                      None, stream_of()))
+        return x
 
     def forward(self, x0, proposals, batch_ids=None):
         """batch_ids: int32 [K] example of every proposal (inference with several examples per batch; the RoI op reads
@@ -607,7 +650,30 @@ class FPNPredictor(nn.Module):
         for l in (self.cls_score, self.bbox_pred):
             nn.init.constant_(l.bias, 0)
 
+    def packed(self):
+        """-> (cls_score and bbox_pred stacked as one packed operand, their biases, classes, version key)"""
+        ps = (self.cls_score.weight, self.cls_score.bias, self.bbox_pred.weight, self.bbox_pred.bias)
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_pack", (None,))[0] != key:
+            w2 = torch.cat([self.cls_score.weight.detach(), self.bbox_pred.weight.detach()], 0)
+            self._pack = (key, _pack_linear(w2), torch.cat([self.cls_score.bias.detach(), self.bbox_pred.bias.detach()]).contiguous())
+        return self._pack[1], self._pack[2], self.cls_score.out_features, key
+
+    def fusable(self, x):
+        return (_mlp_rows_ok(x) and self.cls_score.in_features == x.shape[1]
+                and self.bbox_pred.out_features == 7 * self.cls_score.out_features)
+
     def forward(self, x):
+        if self.fusable(x):
+            w2, b2, a, key = self.packed()
+            done = getattr(x, "_d3d_heads", None)        # computed with fc7 in one launch (FPN2MLPFeatureExtractor)
+            if done is not None and done[0] == key:
+                return done[1], done[2]
+            logits = torch.empty((x.shape[0], a), dtype=torch.float32, device=x.device)
+            reg = torch.empty((x.shape[0], 7 * a), dtype=torch.float32, device=x.device)
+            check(lib().d3d_mlp_heads(ptr(x), x.shape[0], x.shape[1], 0, None, None, None, ptr(w2), ptr(b2), a, ptr(logits),
+                                      ptr(reg), stream_of()))
+            return logits, reg
         return self.cls_score(x), self.bbox_pred(x)
 
 
@@ -786,6 +852,8 @@ class ROIBoxHead3D(nn.Module):
         super().__init__()
         self.feature_extractor = FPN2MLPFeatureExtractor(cfg)
         self.predictor = FPNPredictor(cfg)
+        # fc7 and the predictor share a launch at inference; a plain attribute, not a second registration of the module
+        object.__setattr__(self.feature_extractor, "_heads", self.predictor)
         self.post_processor = PostProcessor(cfg)
 
         self.loss_evaluator = T.ROILoss(cfg)

@@ -157,6 +157,15 @@ int d3d_anchors_maps(d3d_meta *m, int n_maps, const int *sizes_host, const float
 int d3d_rpn_head(const float *const *maps_host, const int *rows_host, int n_maps, int channels,
                  const float *w1_packed, const float *b1, const float *w2_packed, const float *b2, int a,
                  float *objectness, float *regression, void *stream);
+/* a22. The box head behind fc6 at inference (roi_box_feature_extractors.py:110-117, roi_box_predictors.py:33-55) with the
+ * same kernel:  t = relu(relu?(x) W1^T + b1)  [rows, channels];  out_a = t Wa^T + ba  [rows, a];  out_7a = t Wb^T + bb
+ * [rows, 7a]  (a = classes: cls_score and bbox_pred).  x [rows, channels] fp32, channels 128, 256 or 512; relu_in != 0
+ * rectifies x as it is read (fc6's output).  w1_packed / w2_packed / b2 as for d3d_rpn_head; either stage may be left out:
+ * w1_packed == NULL -> the rows are t already (the predictor alone), w2_packed == NULL -> only t_out is written (fc7
+ * alone).  t_out (may be NULL when stage 2 runs) receives t.  One launch for both stages gives the bits of the two
+ * stages launched one after the other.                                                                              */
+int d3d_mlp_heads(const float *x, int rows, int channels, int relu_in, const float *w1_packed, const float *b1,
+                  float *t_out, const float *w2_packed, const float *b2, int a, float *out_a, float *out_7a, void *stream);
 
 /* a4. Metadata::getSubmanifoldRuleBook (Metadata.cpp:430-443; SubmanifoldConvolutionRules.h:27-45).
  * Builds (or finds cached) the rulebook; *n_rules_host = number of (in,out) pairs.           */

@@ -326,6 +326,56 @@ def test_rpn_head_one_launch(dev, config, rows):
         assert torch.allclose(reg, reg_l.detach(), rtol=1e-4, atol=1e-5 * float(wr.abs().max()))
 
 
+@pytest.mark.parametrize("config,rows", [("4c_Fpn432", 1000), ("4c_Fpn432", 37), ("3G6c_Fpn4321", 513), ("4c_Fpn432", 1)])
+def test_box_head_mlp_one_launch(dev, config, rows):
+    """d3d_mlp_heads: relu(fc7(relu(fc6 output))) and the predictor's cls_score / bbox_pred
+    (roi_box_feature_extractors.py:110-117, roi_box_predictors.py:33-55) in ONE launch, against the CPU port's linear
+    layers (1e-4 of the tensor's magnitude: 512-term fp32 sums in another order); the launch with both stages gives the
+    bits of fc7 alone followed by the predictor alone (what the modules do when they are called one by one); updated
+    weights are re-packed; with gradients enabled the library GEMMs run."""
+    from detection_3d_amd.config import get_cfg
+    from detection_3d_amd.detector import ROIBoxHead3D
+    from oracle.detector_port import _lin
+    import torch.nn.functional as F
+    cfg = get_cfg(config)
+    torch.manual_seed(11)
+    box = ROIBoxHead3D(cfg).to(dev).eval()
+    fe, pred = box.feature_extractor, box.predictor
+    assert "_heads" not in dict(fe.named_modules()) and len([k for k in box.state_dict() if "_heads." in k]) == 0
+    for scale in (1.0, 2.0):
+        with torch.no_grad():
+            for p in list(fe.fc7.parameters()) + list(pred.parameters()):
+                p.mul_(scale).add_(0.01 * torch.randn_like(p))
+            h6 = torch.randn(rows, fe.fc7.in_features, device=dev) * 2
+            x = fe._fc7_and_heads(h6)
+            assert getattr(x, "_d3d_heads", None) is not None
+            logits, reg = pred(x)                                  # the pair that rode on x
+            assert logits.data_ptr() == x._d3d_heads[1].data_ptr()
+            x2 = x.clone()                                         # (no attribute: the predictor's own launch)
+            logits2, reg2 = pred(x2)
+            assert torch.equal(logits, logits2) and torch.equal(reg, reg2)
+            object.__setattr__(fe, "_heads", None)
+            try:
+                x3 = fe._fc7_and_heads(h6)                         # fc7 alone
+            finally:
+                object.__setattr__(fe, "_heads", pred)
+            assert torch.equal(x, x3) and getattr(x3, "_d3d_heads", None) is None
+        sd = {"f." + k: v for k, v in fe.state_dict().items()}
+        sd.update({"p." + k: v for k, v in pred.state_dict().items()})
+        wx = F.relu(_lin(sd, "f.fc7", F.relu(h6.cpu())))
+        wl, wr = _lin(sd, "p.cls_score", wx), _lin(sd, "p.bbox_pred", wx)
+        assert logits.shape == wl.shape and reg.shape == wr.shape
+        assert (x.cpu() - wx).abs().max() <= 1e-4 * wx.abs().max()
+        assert (logits.cpu() - wl).abs().max() <= 1e-4 * wl.abs().max()
+        assert (reg.cpu() - wr).abs().max() <= 1e-4 * wr.abs().max()
+        with torch.enable_grad():                                               # the training path: library GEMMs
+            xl = F.relu(fe.fc7(F.relu(h6)))
+            ll, rl = pred(xl)
+        assert getattr(xl, "_d3d_heads", None) is None
+        assert torch.allclose(logits, ll.detach(), rtol=1e-4, atol=1e-5 * float(wl.abs().max()))
+        assert torch.allclose(reg, rl.detach(), rtol=1e-4, atol=1e-5 * float(wr.abs().max()))
+
+
 def test_deferred_proposal_count_matches_the_read_back_path(setup, dev, monkeypatch):
     """The inference tail with the RPN's survivor count left on the device while the pooler is enqueued
     (PaddedProposals, d3d_roi_prepare_counted) against the path that reads the count back first: proposals, their
