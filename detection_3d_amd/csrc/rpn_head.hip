@@ -18,28 +18,41 @@ namespace d3d {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+static constexpr int kRpnMaxSlices = 8;   // channel slices per output tile in stage 2
+
 struct RpnMaps {
   const float *p[D3D_RPN_MAX_MAPS];
   int start[D3D_RPN_MAX_MAPS + 1];  // first row of map m in the row space; start[n_maps] = all rows
   int n_maps;
 };
 
-// wp = packed[g][co][j] = W[co][4g + j] (W in nn.Linear layout [cout, cin]); one 32-column tile at column `colbase`
-template <int C>
+// wp = packed[g][co][j] = W[co][4g + j] (W in nn.Linear layout [cout, cin]); one 32-column tile at column `colbase`,
+// q-iterations [q0, q1) of the C / 8 (8 input channels each).  The weight fragments of QB iterations are requested together
+// (they come straight from L2: one at a time, a 512-channel product waited 64 round trips).
+template <int QB>
 __device__ __forceinline__ f32x16 tile_product(const float *__restrict__ As, int lda, const float *__restrict__ wp,
-                                               int cout, int colbase, int r, int h) {
+                                               int cout, int colbase, int r, int h, int q0, int q1) {
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; i++) acc[i] = 0.f;
   const float *wl = wp + ((size_t)h * cout + colbase + r) * 4;
-#pragma unroll 4
-  for (int q = 0; q < C / 8; q++) {
-    const f32x4 a = *(const f32x4 *)(As + r * lda + q * 8 + h * 4);
-    const f32x4 b = *(const f32x4 *)(wl + (size_t)(2 * q) * cout * 4);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc, 0, 0, 0);
+  for (int qb = q0; qb < q1; qb += QB) {
+    f32x4 b[QB];
+#pragma unroll
+    for (int j = 0; j < QB; j++) {
+      const int q = qb + j < q1 ? qb + j : q1 - 1;      // (a short last batch repeats its last fragment, unused)
+      b[j] = *(const f32x4 *)(wl + (size_t)(2 * q) * cout * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < QB; j++) {
+      if (qb + j < q1) {
+        const f32x4 a = *(const f32x4 *)(As + r * lda + (qb + j) * 8 + h * 4);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[j][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[j][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[j][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[j][3], acc, 0, 0, 0);
+      }
+    }
   }
   return acc;
 }
@@ -56,6 +69,7 @@ __global__ __launch_bounds__(C / 32 * 64) void k_rpn_head(RpnMaps maps, const fl
                                                           float *__restrict__ t_out) {
   constexpr int W = C / 32, LDA = C + 4, LPR = C / 4;
   __shared__ __attribute__((aligned(16))) float As[32 * LDA];
+  __shared__ float Ps[(W < kRpnMaxSlices * 2 ? W : kRpnMaxSlices * 2) * 1024];   // partial 32x32 tiles of stage 2
   const int n = maps.start[maps.n_maps];
   const int row0 = blockIdx.x * 32;
   const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -77,7 +91,7 @@ __global__ __launch_bounds__(C / 32 * 64) void k_rpn_head(RpnMaps maps, const fl
   __syncthreads();
   // C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   if (stages & 1) {
-    const f32x16 acc = tile_product<C>(As, LDA, w1p, C, wib * 32, r, h);
+    const f32x16 acc = tile_product<16>(As, LDA, w1p, C, wib * 32, r, h, 0, C / 8);
     const int col = wib * 32 + r;
     const float bias = b1[col];
     __syncthreads();  // every wave has read the rows
@@ -92,23 +106,33 @@ __global__ __launch_bounds__(C / 32 * 64) void k_rpn_head(RpnMaps maps, const fl
     __syncthreads();
   }
   if (!(stages & 2)) return;
+  // Stage 2: the W waves split the product over (output tile, channel slice): S = W / out_tiles slices per tile (a power
+  // of two), each a partial 32x32 tile in LDS; the partial tiles of an output tile are added in slice order (fixed:
+  // the same bits from a fused launch and from this stage alone).
   const int nout = out_tiles * 32;
-  for (int t = wib; t < out_tiles; t += W) {
-    const f32x16 acc = tile_product<C>(As, LDA, w2p, nout, t * 32, r, h);
-    const int col = t * 32 + r;
-    if (col >= 8 * a) continue;
-    const float bias = b2[col];
+  int S = 1;
+  while (2 * S * out_tiles <= W && 2 * S <= kRpnMaxSlices) S *= 2;
+  const int nq = (C / 8) / S;
+  for (int item = wib; item < out_tiles * S; item += W) {
+    const int t = item / S, sl = item - t * S;
+    const f32x16 acc = tile_product<8>(As, LDA, w2p, nout, t * 32, r, h, sl * nq, (sl + 1) * nq);
+    float *pt = Ps + (size_t)item * 1024;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-      const size_t g = (size_t)row0 + row;
-      if (g >= (size_t)n) continue;
-      const float v = acc[i] + bias;
-      if (col < a)
-        obj[g * a + col] = v;
-      else
-        reg[g * (7 * a) + (col - a)] = v;
-    }
+    for (int i = 0; i < 16; i++) pt[((i & 3) + 8 * (i >> 2) + 4 * h) * 32 + r] = acc[i];
+  }
+  __syncthreads();
+  for (int e = tid; e < out_tiles * 1024; e += W * 64) {
+    const int t = e >> 10, row = (e >> 5) & 31, c = e & 31;
+    const int col = t * 32 + c;
+    const size_t g = (size_t)row0 + row;
+    if (col >= 8 * a || g >= (size_t)n) continue;
+    float v = 0.f;
+    for (int sl = 0; sl < S; sl++) v += Ps[(size_t)(t * S + sl) * 1024 + row * 32 + c];
+    v += b2[col];
+    if (col < a)
+      obj[g * a + col] = v;
+    else
+      reg[g * (7 * a) + (col - a)] = v;
   }
 }
 
@@ -143,6 +167,7 @@ int d3d_rpn_head(const float *const *maps_host, const int *rows_host, int n_maps
   maps.n_maps = n_maps;
   if (n == 0) return D3D_OK;
   const int out_tiles = (8 * a + 31) / 32;
+  D3D_REQUIRE(out_tiles <= channels / 32, "rpn_head: %d output columns for %d channels (at most one 32-column tile per wave)", 8 * a, channels);
   const dim3 grid((unsigned)((n + 31) / 32));
   if (channels == 128)
     hipLaunchKernelGGL((k_rpn_head<128, false>), grid, dim3(256), 0, s, maps, w1_packed, b1, w2_packed, b2, a, out_tiles,
@@ -174,6 +199,7 @@ int d3d_mlp_heads(const float *x, int rows, int channels, int relu_in, const flo
   maps.start[D3D_RPN_MAX_MAPS] = rows;
   maps.n_maps = 1;
   const int out_tiles = w2_packed ? (8 * a + 31) / 32 : 0;
+  D3D_REQUIRE(out_tiles <= channels / 32, "mlp_heads: %d output columns for %d channels", 8 * a, channels);
   const dim3 grid((unsigned)((rows + 31) / 32));
 #define D3D_MLP_LAUNCH(CC, RI)                                                                                         \
   hipLaunchKernelGGL((k_rpn_head<CC, RI>), grid, dim3(CC / 32 * 64), 0, s, maps, w1_packed, b1, w2_packed, b2, a, out_tiles, \

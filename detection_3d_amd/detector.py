@@ -102,7 +102,10 @@ def build_backbone(cfg):
 
 _ANCHORS_ONE_LAUNCH = os.environ.get("D3D_ANCHOR_LAUNCHES", "one") != "per-map"
 _FUSED_RPN_HEAD = os.environ.get("D3D_RPN_HEAD", "fused") != "gemm"     # "gemm": the library-GEMM form, for A/B runs
-_FUSED_BOX_MLP = os.environ.get("D3D_BOX_MLP", "fused") != "gemm"       # ... of fc7 and the predictor behind fc6
+# fc7 and the predictor behind fc6 as ONE launch (d3d_mlp_heads) instead of two activations and three library GEMMs: off by
+# default -- a workgroup owns 32 rows and all 512 columns, so 1000 proposals occupy 32 CUs, whose matrix cores need 27 us
+# for the product; the launch takes 47 us against 37 us for the five (D3D_BOX_MLP=fused switches it on)
+_FUSED_BOX_MLP = os.environ.get("D3D_BOX_MLP", "gemm") == "fused"
 
 
 # ----------------------------------------------------------------------------------------------

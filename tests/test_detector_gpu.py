@@ -327,16 +327,18 @@ def test_rpn_head_one_launch(dev, config, rows):
 
 
 @pytest.mark.parametrize("config,rows", [("4c_Fpn432", 1000), ("4c_Fpn432", 37), ("3G6c_Fpn4321", 513), ("4c_Fpn432", 1)])
-def test_box_head_mlp_one_launch(dev, config, rows):
+def test_box_head_mlp_one_launch(dev, config, rows, monkeypatch):
     """d3d_mlp_heads: relu(fc7(relu(fc6 output))) and the predictor's cls_score / bbox_pred
     (roi_box_feature_extractors.py:110-117, roi_box_predictors.py:33-55) in ONE launch, against the CPU port's linear
     layers (1e-4 of the tensor's magnitude: 512-term fp32 sums in another order); the launch with both stages gives the
     bits of fc7 alone followed by the predictor alone (what the modules do when they are called one by one); updated
     weights are re-packed; with gradients enabled the library GEMMs run."""
     from detection_3d_amd.config import get_cfg
+    from detection_3d_amd import detector
     from detection_3d_amd.detector import ROIBoxHead3D
     from oracle.detector_port import _lin
     import torch.nn.functional as F
+    monkeypatch.setattr(detector, "_FUSED_BOX_MLP", True)     # (off by default: measured slower than the library GEMMs)
     cfg = get_cfg(config)
     torch.manual_seed(11)
     box = ROIBoxHead3D(cfg).to(dev).eval()
