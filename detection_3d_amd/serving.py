@@ -18,6 +18,7 @@ hide their read-back latencies.  Results are
 bit-identical to the serial loop (tests/test_detector_gpu.py); the reference has no counterpart (its test loop,
 maskrcnn_benchmark/engine/inference.py:17-40 `compute_on_dataset`, is serial).
 """
+import os
 import queue
 import threading
 
@@ -32,7 +33,10 @@ class BuildingPipeline(object):
         self.device = device if device is not None else next(model.parameters()).device
         self.in_flight = max(1, int(in_flight))
         # streams live as long as the pipeline: metadata arenas and scratch buffers are recycled per stream
-        self.hi = [torch.cuda.Stream(device=self.device, priority=-1) for _ in range(self.in_flight)]
+        # (normal queue priority: as high-priority streams the geometry / tail stages held back the other building's feature
+        #  pass on some boxes -- 203-208 against 204-216 buildings/s in pairs of runs; D3D_PIPE_PRIORITY=-1 restores it)
+        prio = int(os.environ.get("D3D_PIPE_PRIORITY", "0"))
+        self.hi = [torch.cuda.Stream(device=self.device, priority=prio) for _ in range(self.in_flight)]
         self.lo = [torch.cuda.Stream(device=self.device) for _ in range(self.in_flight)]
 
     def map(self, clouds):
