@@ -9,9 +9,9 @@ convolutions over a few hundred rows, the detector tail reads two counts back an
     stage 2  features  (sparse-conv FPN; enqueue only, never waits for the GPU)       the calling thread
     stage 3  tail      (RPN decode + NMS, RoIAlign, box head, per-class NMS)          thread "tail"
 
-Building i owns slot i % in_flight: a high-priority HIP stream for its geometry and tail stages (chains of small
-dependent kernels whose latency sets the pipeline's rate -- they must not queue behind another building's 200-us
-convolutions) and a normal-priority stream for its feature pass, chained by events; its own metadata arena and scratch
+Building i owns slot i % in_flight: a HIP stream for its geometry and tail stages (chains of small dependent kernels
+whose latency sets the pipeline's rate; normal queue priority -- high priority, round 2's choice, helped on some boxes and
+held the other building's convolutions back on others) and a stream for its feature pass, chained by events; its own metadata arena and scratch
 (SCN._scratch_key), so no two buildings share mutable state; a semaphore bounds the buildings in flight.  While one
 building's large convolutions run, the next one's geometry kernels and the previous one's tail fill the idle CUs and
 hide their read-back latencies.  Results are
