@@ -38,6 +38,7 @@ _SIGS = {
     "d3d_grid_chain_enable": (ctypes.c_int, [ctypes.c_int]),
     "d3d_conv_ws_mode": (ctypes.c_int, [ctypes.c_int]),
     "d3d_conv_late_mode": (ctypes.c_int, [ctypes.c_int]),
+    "d3d_conv_dw_deterministic": (ctypes.c_int, [ctypes.c_int]),
     "d3d_grid_chain_head": (ctypes.c_int, [ctypes.c_int]),
     "d3d_sort_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "d3d_sort_pairs": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_size_t, vp]),

@@ -43,7 +43,10 @@ static constexpr int kDwMaxChunk = 8;
 // the 32 dOut rows) go through registers one block ahead and their row indices two blocks ahead, all loads
 // branch-free (an absent row reads row 0 and is zeroed on the way to LDS), so the gathers of the next block fly
 // under the MFMAs of the current one -- the same pipeline as the forward kernel.
-template <int CP, int COUT>
+// DET (d3d_conv_dw_deterministic): no atomics.  Workgroup blockIdx.x walks the runs blockIdx.x, + gridDim.x, ... in order
+// (all of a run's active blocks, no chunks), keeps the sum in its accumulators and STORES it as partial `blockIdx.x` of
+// dW (zeros when it met no rule); k_dw_reduce adds the partials to dW in a fixed order.
+template <int CP, int COUT, bool DET>
 __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ in, int cin,
                                                  const float *__restrict__ d_out,
                                                  const int32_t *__restrict__ nbrT, int npos,
@@ -61,14 +64,19 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ in, i
   const int k = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = lane & 31, kk = lane >> 5;
-  const int b0 = blockIdx.x * run;
-  // blocks of this run (<= 64) that have a rule at offset k
-  const uint32_t mymask = (lane < run && b0 + lane < n_blk) ? blkmask[b0 + lane] : 0u;
-  unsigned long long active = __ballot((mymask >> k) & 1u);
+  int b0 = blockIdx.x * run;
+  const int n_runs = (n_blk + run - 1) / run;
+  int rx = blockIdx.x;            // the run being walked (DET: then rx + gridDim.x, ...)
+  // blocks of a run (<= 64) that have a rule at offset k
+  auto run_mask = [&](int first) -> unsigned long long {
+    const uint32_t mm = (lane < run && first + lane < n_blk) ? blkmask[first + lane] : 0u;
+    return __ballot((mm >> k) & 1u);
+  };
+  unsigned long long active = run_mask(b0);
   // The run's active blocks are dealt out in chunks of `chunk` to the workgroups blockIdx.z / nz_tiles = 0, 1, ...:
   // a dense offset (the centre one is present in every block) no longer makes one workgroup walk the whole run
   // while the workgroups of the sparse offsets have long finished.
-  {
+  if constexpr (!DET) {
     const int c = blockIdx.z / nz_tiles;
     for (int d = 0; d < c * chunk && active; d++) active &= active - 1;
     unsigned long long keep = 0, rest = active;
@@ -78,7 +86,9 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ in, i
     }
     active = keep;
   }
-  if (!active) return;
+  if constexpr (!DET) {
+    if (!active) return;
+  }
   const int zt = blockIdx.z % nz_tiles;   // tile group
   f32x16 acc[TPW];
 #pragma unroll
@@ -144,16 +154,27 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ in, i
       if (e < 32 * B4) *(f32x4 *)(Bs + (e / B4) * COUT + (e % B4) * 4) = ((real_b >> j) & 1u) ? sb[j] : zero;
     }
   };
-  auto pop = [&]() -> int {  // next active block of the run, or -1
-    if (!active) return -1;
+  auto pop = [&]() -> int {  // next active block of the run (DET: of this workgroup's runs), or -1
+    if constexpr (DET) {
+      while (!active) {        // (uniform over the workgroup: every wave walks the same runs)
+        rx += gridDim.x;
+        if (rx >= n_runs) return -1;
+        b0 = rx * run;
+        active = run_mask(b0);
+      }
+    } else {
+      if (!active) return -1;
+    }
     const int j = __builtin_ctzll(active);
     active &= active - 1;
     return b0 + j;
   };
 
   int bc = pop();               // block being computed
-  load_idx(bc);
-  issue_data();
+  if (bc >= 0) {
+    load_idx(bc);
+    issue_data();
+  }
   int bn = pop();               // block whose operands are requested during bc's MFMAs
   if (bn >= 0) load_idx(bn);
   while (bc >= 0) {
@@ -189,21 +210,61 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ in, i
     for (int reg = 0; reg < 16; reg++) {
       const int ci = ti * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kk;
       const int co = tj * 32 + i;
-      if (ci < cin) atomicAdd(dW + ((size_t)k * cin + ci) * COUT + co, acc[t][reg]);
+      if constexpr (DET) {
+        if (ci < cin) dW[(((size_t)blockIdx.x * gridDim.y + k) * cin + ci) * COUT + co] = acc[t][reg];
+      } else {
+        if (ci < cin) atomicAdd(dW + ((size_t)k * cin + ci) * COUT + co, acc[t][reg]);
+      }
     }
   }
 }
 
+// dW[e] += partial[0][e] + partial[1][e] + ...  (in that order)
+__global__ __launch_bounds__(256) void k_dw_reduce(const float *__restrict__ part, int n_part, size_t n, float *__restrict__ dW) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  float v = 0.f;
+  for (int g = 0; g < n_part; g++) v += part[(size_t)g * n + e];
+  dW[e] += v;
+}
+
+static bool g_dw_deterministic = [] {
+  const char *e = getenv("D3D_DW_DETERMINISTIC");
+  return e && e[0] != '0';
+}();
+static constexpr int kDwDetPartials = 32;   // workgroups (and partial sums) per offset and tile group in deterministic mode
+
 template <int CP, int COUT>
-static int launch_dw_t(const Plan &p, const float *in, int cin, const float *d_out, float *dW, hipStream_t s) {
+static int launch_dw_t(d3d_meta *m, const Plan &p, const float *in, int cin, const float *d_out, float *dW, hipStream_t s) {
   constexpr int T = (CP / 32) * (COUT / 32);
   constexpr int TPG = T < 16 ? T : 16;
+  const int nz = (T + TPG - 1) / TPG;
+  if (g_dw_deterministic) {
+    // fixed summation order: run r belongs to workgroup r % G, which adds its runs' blocks in order; the G partial
+    // sums are added in order by k_dw_reduce.  Scratch: G x (K, cin, COUT) floats of the feature lane.
+    D3D_REQUIRE(m, "deterministic conv backward needs the metadata (its scratch lane)");
+    const int run = kDwBlocksPerWg;
+    const int n_runs = (p.n_blk + run - 1) / run;
+    const int G = std::min(n_runs, kDwDetPartials);
+    const size_t n = (size_t)p.K * cin * COUT;
+    const size_t mark = m->feat_arena.used;
+    float *part = m->feat_arena.get<float>((size_t)G * n);
+    if (!part) {
+      set_error("deterministic conv backward: %zu bytes of scratch do not fit the feature lane", (size_t)G * n * 4);
+      return D3D_ERR_NOMEM;
+    }
+    hipLaunchKernelGGL((k_conv_dw<CP, COUT, true>), dim3(G, p.K, nz), dim3(256), 0, s, in, cin, d_out, p.nbrT, p.n_blk * 32,
+                       p.rows, p.blkmask, p.n_blk, run, run, nz, part);
+    hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, G, n, dW);
+    m->feat_arena.used = mark;   // stream-ordered scratch
+    D3D_LAUNCH_CHECK();
+    return D3D_OK;
+  }
   // run length: long runs amortise the final atomics of a workgroup (T * 1024 of them), short runs keep a small
   // plan from being walked serially by a handful of workgroups -- aim at >= kDwTargetWgs workgroups.  Plans so large
   // that the run hits the 64 blocks one ballot covers deal the run's active blocks out in chunks of kDwMaxChunk
   // instead: the dense offsets (the centre one is in every block) would otherwise set the kernel's duration
   // (measured: Cin = Cout = 64 at 370 k rows 236 -> 186 us, 32 at 460 k rows 124 -> 90 us; smaller plans lose).
-  const int nz = (T + TPG - 1) / TPG;
   long run = ((long)p.n_blk * p.K * nz + kDwTargetWgs - 1) / kDwTargetWgs;
   long chunk;
   if (run >= kDwBlocksPerWg) {
@@ -215,30 +276,32 @@ static int launch_dw_t(const Plan &p, const float *in, int cin, const float *d_o
   }
   const int n_chunks = (int)((run + chunk - 1) / chunk);
   dim3 grid((unsigned)((p.n_blk + run - 1) / run), p.K, nz * n_chunks);
-  hipLaunchKernelGGL((k_conv_dw<CP, COUT>), grid, dim3(256), 0, s, in, cin, d_out, p.nbrT, p.n_blk * 32, p.rows,
+  hipLaunchKernelGGL((k_conv_dw<CP, COUT, false>), grid, dim3(256), 0, s, in, cin, d_out, p.nbrT, p.n_blk * 32, p.rows,
                      p.blkmask, p.n_blk, (int)run, (int)chunk, nz, dW);
   D3D_LAUNCH_CHECK();
   return D3D_OK;
 }
 template <int CP>
-static int launch_dw_c(const Plan &p, const float *in, int cin, const float *d_out, int cout, float *dW, hipStream_t s) {
+static int launch_dw_c(d3d_meta *m, const Plan &p, const float *in, int cin, const float *d_out, int cout, float *dW,
+                       hipStream_t s) {
   switch (cout) {
-    case 32: return launch_dw_t<CP, 32>(p, in, cin, d_out, dW, s);
-    case 64: return launch_dw_t<CP, 64>(p, in, cin, d_out, dW, s);
-    case 128: return launch_dw_t<CP, 128>(p, in, cin, d_out, dW, s);
-    case 256: return launch_dw_t<CP, 256>(p, in, cin, d_out, dW, s);
+    case 32: return launch_dw_t<CP, 32>(m, p, in, cin, d_out, dW, s);
+    case 64: return launch_dw_t<CP, 64>(m, p, in, cin, d_out, dW, s);
+    case 128: return launch_dw_t<CP, 128>(m, p, in, cin, d_out, dW, s);
+    case 256: return launch_dw_t<CP, 256>(m, p, in, cin, d_out, dW, s);
   }
   set_error("conv backward: Cout=%d not supported", cout);
   return D3D_ERR_UNSUPPORTED;
 }
 // dW[K, cin, cout] += ...   (dW pre-zeroed by the caller, like the reference's d_weight)
-static int launch_dw(const Plan &p, const float *in, int cin, const float *d_out, int cout, float *dW, hipStream_t s) {
+static int launch_dw(d3d_meta *m, const Plan &p, const float *in, int cin, const float *d_out, int cout, float *dW,
+                     hipStream_t s) {
   if (p.n_rows == 0) return D3D_OK;
   D3D_REQUIRE(in && d_out && dW, "conv backward: null pointer");
-  if (cin <= 32) return launch_dw_c<32>(p, in, cin, d_out, cout, dW, s);
-  if (cin <= 64) return launch_dw_c<64>(p, in, cin, d_out, cout, dW, s);
-  if (cin <= 128) return launch_dw_c<128>(p, in, cin, d_out, cout, dW, s);
-  if (cin <= 256) return launch_dw_c<256>(p, in, cin, d_out, cout, dW, s);
+  if (cin <= 32) return launch_dw_c<32>(m, p, in, cin, d_out, cout, dW, s);
+  if (cin <= 64) return launch_dw_c<64>(m, p, in, cin, d_out, cout, dW, s);
+  if (cin <= 128) return launch_dw_c<128>(m, p, in, cin, d_out, cout, dW, s);
+  if (cin <= 256) return launch_dw_c<256>(m, p, in, cin, d_out, cout, dW, s);
   set_error("conv backward: Cin=%d not supported", cin);
   return D3D_ERR_UNSUPPORTED;
 }
@@ -492,7 +555,7 @@ int d3d_subm_conv_backward(d3d_meta *m, const int *size, const int *filt, const 
     rc = launch_conv(m, *p, d_out, cout, packed_wt_flipped, cin, nullptr, d_in, s);
     if (rc) return rc;
   }
-  if (d_weight) return launch_dw(*p, in, cin, d_out, cout, d_weight, s);
+  if (d_weight) return launch_dw(m, *p, in, cin, d_out, cout, d_weight, s);
   return D3D_OK;
 }
 
@@ -513,7 +576,7 @@ int d3d_conv_backward(d3d_meta *m, const int *in_size, const int *out_size, cons
     rc = launch_conv(m, *dec, d_out, cout, packed_wt, cin, nullptr, d_in, s);
     if (rc) return rc;
   }
-  if (d_weight) return launch_dw(*fwd, in, cin, d_out, cout, d_weight, s);
+  if (d_weight) return launch_dw(m, *fwd, in, cin, d_out, cout, d_weight, s);
   return D3D_OK;
 }
 
@@ -535,9 +598,15 @@ int d3d_deconv_backward(d3d_meta *m, const int *in_size, const int *out_size, co
     const Plan *dec = nullptr;
     int rc = get_deconv_plan(m, out_size, filt, stride, s, &dec);
     if (rc) return rc;
-    return launch_dw(*dec, in, cin, d_out, cout, d_weight, s);
+    return launch_dw(m, *dec, in, cin, d_out, cout, d_weight, s);
   }
   return D3D_OK;
+}
+
+int d3d_conv_dw_deterministic(int on) {
+  const int was = g_dw_deterministic ? 1 : 0;
+  if (on >= 0) g_dw_deterministic = on != 0;
+  return was;
 }
 
 size_t d3d_bn_backward_scratch_bytes(int planes) {

@@ -159,3 +159,54 @@ def test_dense_roi_align_and_sparse_to_dense_backward(dev):
     assert rel(grads[0][1], grads[1][1]) < 1e-4
     want = oracle.roi_align_rotated_3d_backward(g.cpu().numpy(), rois, 0.25, 6, 8, 4, 2, (1, 64, 32, 32, 8))
     assert rel(grads[0][1], want[0][:, loc[:, 0], loc[:, 1], loc[:, 2]].T) < 1e-4
+
+
+@pytest.mark.parametrize("cin,cout,n_points", [(32, 32, 60000), (64, 64, 60000), (128, 128, 20000), (64, 128, 3000), (256, 256, 300)])
+def test_conv_backward_deterministic_dw(dev, cin, cout, n_points):
+    """d3d_conv_dw_deterministic(1): dWeight without atomics -- the same bits in every run (the default accumulates with
+    fp32 atomics like the reference, SCN/CUDA/Convolution.cu:249-442, and differs in the last bits from run to run), equal
+    to the atomic form up to summation order (1e-5 of the tensor's magnitude) and to the oracle like it (2e-4).
+    Submanifold 3x3x3, strided 2/2 and its deconvolution; plans of one run and of several runs per workgroup."""
+    from detection_3d_amd import sparseconvnet as scn
+    from detection_3d_amd._lib import lib
+    from tests.helpers import nbr_to_rules
+    size = (128, 128, 32)
+    rng = np.random.RandomState(cin + cout)
+    _, coords, _ = small_scene(5, n_points, (2.5, 2.0, 0.6), size)
+    feats = torch.from_numpy(rng.randn(coords.shape[0], cin).astype(np.float32)).to(dev)
+    torch.manual_seed(3)
+    sub = scn.SubmanifoldConvolution(3, cin, cout, 3, False).to(dev)
+    down = scn.Convolution(3, cin, cout, [2, 2, 2], [2, 2, 2], False).to(dev)
+    up = scn.Deconvolution(3, cout, cin, [2, 2, 2], [2, 2, 2], False).to(dev)
+
+    def grads():
+        for m in (sub, down, up):
+            m.weight.grad = None
+        t = scn.InputLayer(3, size, mode=4)([torch.from_numpy(coords), feats])
+        y = sub(t).features
+        y.backward(torch.ones_like(y) * 0.5 + y.detach() * 0.1)
+        u = up(down(t)).features
+        u.backward(torch.ones_like(u) * 0.25 + u.detach() * 0.1)
+        return [m.weight.grad.clone() for m in (sub, down, up)], t
+
+    atomic, t = grads()
+    was = lib().d3d_conv_dw_deterministic(1)
+    try:
+        a, _ = grads()
+        b, _ = grads()
+    finally:
+        lib().d3d_conv_dw_deterministic(was)
+    for x, y, z in zip(a, b, atomic):
+        assert torch.isfinite(x).all() and float(x.abs().max()) > 0
+        assert torch.equal(x, y)                                              # bit-stable
+        assert float((x - z).abs().max()) <= 1e-5 * float(z.abs().max())      # the atomic form, another order
+    # ... and the oracle, for the submanifold layer
+    sop, loc = oracle.input_sites(coords)
+    xin = oracle.input_forward(feats.cpu().numpy(), sop, loc.shape[0], True)
+    nbr, _ = oracle.subm_nbr(loc, [3, 3, 3])
+    w = sub.weight.detach().cpu().numpy().reshape(27, cin, cout)
+    rules = nbr_to_rules(nbr)
+    yo = oracle.rule_conv(xin, w, rules, loc.shape[0])
+    g = (0.5 + 0.1 * yo).astype(np.float32)
+    _, d_w = oracle.rule_conv_backward(xin, w, rules, g)
+    assert rel(a[0].cpu().numpy().reshape(27, cin, cout), d_w) < 2e-4
