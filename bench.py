@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=500_000)
     ap.add_argument("--scenes", type=int, default=4, help="distinct synthetic scenes cycled per rank")
+    ap.add_argument("--profile-every", type=int, default=int(os.environ.get("D3D_BENCH_SAMPLE", "5")),
+                    help="HIP events around the dominant convolution family's launches in every n-th timed pass")
     ap.add_argument("--in-flight", type=int, default=2, help="buildings in flight of the extra `pipelined` region (1: skip it)")
     ap.add_argument("--no-bf16", action="store_true", help="skip the extra `bf16_bs4` region (BASELINE.json configs[4])")
     ap.add_argument("--bf16-points", type=int, default=1_000_000)
@@ -273,6 +275,9 @@ def main():
     if warm:
         prof.focus = {max(warm.items(), key=lambda kv: kv[1]["ms"])[0]}
     prof.records = []
+    # the timed region records events around the dominant family's launches of every `--profile-every`-th pass (two
+    # records per launch, ~0.1 ms per pass at 20 launches): the roofline's average is over those passes' launches
+    prof.sample_every, prof.sampled, prof._started = max(1, args.profile_every), 0, 0
     if warm:    # the events of the timed region's launches, created ahead of it
         prof.reserve(2 * (warm[next(iter(prof.focus))]["calls"] // max(args.warmup, 1) + 1) * args.steps)
     barrier()
@@ -347,14 +352,15 @@ def main():
                 sel = [(f, s_.elapsed_time(e_)) for k_, f, _b, s_, e_ in prof.records if k_ == key and lo <= f < hi]
                 if sel:
                     fl, ms = sum(f for f, _ in sel), sum(m for _, m in sel)
-                    buckets.append({"launches_of": tag, "launches_per_step": len(sel) / args.steps,
+                    buckets.append({"launches_of": tag, "launches_per_step": len(sel) / max(prof.sampled, 1),
                                     "share_of_time": round(ms / d["ms"], 3), "tflops": round(fl / (ms * 1e-3) / 1e12, 1),
                                     "frac": round(fl / (ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4)})
             roof = {"bound": "mfma", "achieved": round(tflops, 3), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tflops / FP32_MATRIX_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_unit": traffic_src,
                     "kernel": kernel_name(key),
-                    "launches_per_step": d["calls"] / args.steps, "avg_launch_us": round(per_launch_ms * 1e3, 1),
+                    "launches_per_step": d["calls"] / max(prof.sampled, 1), "avg_launch_us": round(per_launch_ms * 1e3, 1),
+                    "timed_passes": prof.sampled,
                     "algorithmic_gflop_per_launch": round(d["flops"] / d["calls"] / 1e9, 3),
                     "compulsory_GBps": round(gbs, 1), "compulsory_frac_of_hbm": round(gbs / HBM_PEAK_GBS, 4),
                     "all_sparse_conv_ms_per_step_warmup": None if conv_ms_warm is None else round(conv_ms_warm, 3),

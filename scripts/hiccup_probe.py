@@ -24,13 +24,19 @@ def run(tag):
             model(list(voxelize(scenes[i % 4], s.VOXEL_SCALE, s.VOXEL_FULL_SCALE)))
         torch.cuda.synchronize()
         t = time.perf_counter()
+        allocs = []
         for i in range(N):
+            a0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
             model(list(voxelize(scenes[i % 4], s.VOXEL_SCALE, s.VOXEL_FULL_SCALE)))
             t2 = time.perf_counter()
             ts.append(1e3 * (t2 - t))
-            t = t2
+            allocs.append(torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - a0)
+            t = time.perf_counter()
     a = sorted(ts)
     slow = [round(x, 1) for x in ts if x > 1.25 * a[len(a) // 2]]
+    med = a[len(a) // 2]
+    print(f"   device allocations in the timed passes: {sum(allocs)}; in the slow passes: "
+          f"{[(round(x, 1), n) for x, n in zip(ts, allocs) if x > 1.25 * med]}", flush=True)
     print(f"{tag}: mean {sum(ts) / len(ts):.3f} median {a[len(a) // 2]:.3f} p99 {a[int(0.99 * len(a))]:.3f} max {a[-1]:.3f}; "
           f"{len(slow)} passes over 1.25 x median: {slow[:12]}; gc counts {gc.get_count()}", flush=True)
 
