@@ -7,7 +7,7 @@
 #include <cstdlib>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-template <int WPB, int NQ, int QA, bool WLOAD, bool GATHER, int NV>
+template <int WPB, int NQ, int QA, bool WLOAD, bool GATHER, int NV, bool PRO = false, bool IDXL = false>
 __global__ __launch_bounds__(WPB * 64) void k(float *out, int steps, const float *__restrict__ wbuf, const float *__restrict__ rows,
                                              const int *__restrict__ ridx, int n_rows) {
   constexpr int CIN = NQ * 8, COUT = WPB * 32, LDA = CIN + 4, LPR = CIN / 4, RPP = WPB * 64 / LPR, NIT = 32 / RPP;
@@ -33,6 +33,21 @@ __global__ __launch_bounds__(WPB * 64) void k(float *out, int steps, const float
   }
   f32x4 stage[NIT > 0 ? NIT : 1];
   int bi = blockIdx.x * 32;
+  int idx[NIT > 0 ? NIT : 1];
+#pragma unroll
+  for (int it = 0; it < NIT; it++) idx[it] = (bi + it * RPP + grow) % n_rows;
+  if (PRO) {
+    // the chain a block of k_conv starts with: mask word -> (dependent) indices -> (dependent) rows -> commit
+    const int m = __builtin_amdgcn_readfirstlane(ridx[blockIdx.x % n_rows]);
+    kk = (kk + (m & 1)) % 27;
+#pragma unroll
+    for (int it = 0; it < NIT; it++) idx[it] = ridx[(m + bi + it * RPP + grow) % n_rows];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) stage[it] = *(const f32x4 *)(rows + (size_t)idx[it] * CIN + gc4 * 4);
+#pragma unroll
+    for (int it = 0; it < NIT; it++) *(f32x4 *)(As + (it * RPP + grow) * LDA + gc4 * 4) = stage[it];
+    __syncthreads();
+  }
   for (int st = 0; st < steps; st++) {
     const int nk = (kk + 1) % 27;
     if (GATHER && st > 0) {
@@ -45,10 +60,14 @@ __global__ __launch_bounds__(WPB * 64) void k(float *out, int steps, const float
     if (GATHER) {
 #pragma unroll
       for (int it = 0; it < NIT; it++) {
-        const int row = ridx[(bi + it * RPP + grow) % n_rows];
+        const int row = IDXL ? idx[it] : ridx[(bi + it * RPP + grow) % n_rows];
         stage[it] = *(const f32x4 *)(rows + (size_t)row * CIN + gc4 * 4);
       }
       bi += 32 * 977;
+      if (IDXL) {     // the indices of the step after next (a load the NEXT step's gather addresses depend on)
+#pragma unroll
+        for (int it = 0; it < NIT; it++) idx[it] = ridx[(bi + it * RPP + grow) % n_rows];
+      }
     }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -79,8 +98,8 @@ __global__ __launch_bounds__(WPB * 64) void k(float *out, int steps, const float
 static float *g_w, *g_rows, *g_out;
 static int *g_idx;
 static const int kRows = 400000;
-template <int WPB, int NQ, int QA, bool WLOAD, bool GATHER, int NV>
-void run(int waves_per_simd, const char *tag) {
+template <int WPB, int NQ, int QA, bool WLOAD, bool GATHER, int NV, bool PRO = false, bool IDXL = false>
+void run(int waves_per_simd, const char *tag, int steps_arg = 16) {
   const int blocks = 256 * 4 * 4 / WPB * 6;     // six rounds at 4 waves per SIMD
   const size_t dyn = waves_per_simd >= 4 ? 0 : (waves_per_simd == 3 ? 40 : waves_per_simd == 2 ? 70 : 150) * 1024 / (16 / WPB > 0 ? 1 : 1);   // dynamic LDS that limits the resident workgroups
   // resident waves per SIMD = 160 KB / (static + dynamic LDS per block) * WPB / 4
@@ -89,13 +108,13 @@ void run(int waves_per_simd, const char *tag) {
   size_t lds_per_block = waves_per_simd >= 4 ? 0 : (size_t)160 * 1024 / (want_blocks_per_cu + 0) - stat - 512;
   if (lds_per_block > 60 * 1024) lds_per_block = 60 * 1024;
   (void)dyn;
-  const int steps = 16;                                      // as a block of k_conv: ~16 active offsets
+  const int steps = steps_arg;                                      // as a block of k_conv: ~16 active offsets
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  hipLaunchKernelGGL((k<WPB, NQ, QA, WLOAD, GATHER, NV>), dim3(blocks), dim3(WPB * 64), lds_per_block, 0, g_out, steps, g_w, g_rows, g_idx, kRows);
+  hipLaunchKernelGGL((k<WPB, NQ, QA, WLOAD, GATHER, NV, PRO, IDXL>), dim3(blocks), dim3(WPB * 64), lds_per_block, 0, g_out, steps, g_w, g_rows, g_idx, kRows);
   (void)hipEventRecord(e0);
   for (int rep = 0; rep < 5; rep++)
-    hipLaunchKernelGGL((k<WPB, NQ, QA, WLOAD, GATHER, NV>), dim3(blocks), dim3(WPB * 64), lds_per_block, 0, g_out, steps, g_w, g_rows, g_idx, kRows);
+    hipLaunchKernelGGL((k<WPB, NQ, QA, WLOAD, GATHER, NV, PRO, IDXL>), dim3(blocks), dim3(WPB * 64), lds_per_block, 0, g_out, steps, g_w, g_rows, g_idx, kRows);
   (void)hipEventRecord(e1);
   (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -113,12 +132,14 @@ int main() {
   srand(1);
   for (int i = 0; i < kRows; i++) hidx[i] = rand() % kRows;
   (void)hipMemcpy(g_idx, hidx, kRows * 4, hipMemcpyHostToDevice);
-  for (int w : {4, 3, 2, 1}) {
-    printf("--- %d waves per SIMD resident\n", w);
-    run<2, 8, 8, false, false, 64>(w, "64->64 structure only (short blocks)");
-    run<2, 8, 8, true, true, 64>(w, "64->64 + weights + gathered rows");
-    run<4, 16, 8, false, false, 64>(w, "128->128 structure only (short blocks)");
-    run<4, 16, 8, true, true, 64>(w, "128->128 + weights + gathered rows");
-  }
+  run<2, 8, 8, true, true, 64>(4, "64->64 weights + rows");
+  run<2, 8, 8, true, true, 64, false, true>(4, "64->64 ... + index loads");
+  run<2, 8, 8, true, true, 64, true, true>(4, "64->64 ... + index loads + block prologue");
+  run<2, 8, 8, true, true, 64, true, true>(4, "64->64 ... the same, blocks of 8 steps", 8);
+  run<2, 8, 8, true, true, 64, true, true>(4, "64->64 ... the same, blocks of 27 steps", 27);
+  run<4, 16, 8, true, true, 64>(4, "128->128 weights + rows");
+  run<4, 16, 8, true, true, 64, false, true>(4, "128->128 ... + index loads");
+  run<4, 16, 8, true, true, 64, true, true>(4, "128->128 ... + index loads + block prologue");
+  run<4, 16, 8, true, true, 64, true, true>(4, "128->128 ... the same, blocks of 8 steps", 8);
   return 0;
 }
