@@ -10,6 +10,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int WPB, int NQ, int QA, bool WLOAD, bool GATHER, int NV, bool PRO = false, bool IDXL = false>
 __global__ __launch_bounds__(WPB * 64) void k(float *out, int steps, const float *__restrict__ wbuf, const float *__restrict__ rows,
                                              const int *__restrict__ ridx, int n_rows) {
+  static_assert(NQ * 8 <= 128 && WPB * 32 <= 128, "the probe's arrays hold 128-channel rows and 27 x 128 x 128 weights");
   constexpr int CIN = NQ * 8, COUT = WPB * 32, LDA = CIN + 4, LPR = CIN / 4, RPP = WPB * 64 / LPR, NIT = 32 / RPP;
   __shared__ __attribute__((aligned(16))) float As[32 * LDA];
   f32x16 acc;
@@ -132,14 +133,9 @@ int main() {
   srand(1);
   for (int i = 0; i < kRows; i++) hidx[i] = rand() % kRows;
   (void)hipMemcpy(g_idx, hidx, kRows * 4, hipMemcpyHostToDevice);
-  run<2, 8, 8, true, true, 64>(4, "64->64 weights + rows");
-  run<2, 8, 8, true, true, 64, false, true>(4, "64->64 ... + index loads");
-  run<2, 8, 8, true, true, 64, true, true>(4, "64->64 ... + index loads + block prologue");
-  run<2, 8, 8, true, true, 64, true, true>(4, "64->64 ... the same, blocks of 8 steps", 8);
-  run<2, 8, 8, true, true, 64, true, true>(4, "64->64 ... the same, blocks of 27 steps", 27);
-  run<4, 16, 8, true, true, 64>(4, "128->128 weights + rows");
-  run<4, 16, 8, true, true, 64, false, true>(4, "128->128 ... + index loads");
-  run<4, 16, 8, true, true, 64, true, true>(4, "128->128 ... + index loads + block prologue");
-  run<4, 16, 8, true, true, 64, true, true>(4, "128->128 ... the same, blocks of 8 steps", 8);
+  run<2, 8, 8, false, false, 64>(4, "64->64 structure only, 8 q per barrier pair");
+  run<2, 16, 8, false, false, 128>(4, "64->64 structure only, 16 q per barrier pair", 8);
+  run<2, 8, 8, true, true, 64, true, true>(4, "64->64 all traffic, 8 q per barrier pair");
+  run<2, 16, 8, true, true, 128, true, true>(4, "64->64 all traffic, 16 q per barrier pair", 8);
   return 0;
 }
